@@ -1,0 +1,19 @@
+#!/usr/bin/env bash
+# Build the HIP library for gfx950 (cross-compiles without a GPU).  Output: ../libfvp_hip.so
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${here}/../libfvp_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+srcs=(fvp_capi.hip fvp_project.hip fvp_conv.hip fvp_proposal.hip fvp_joint.hip)
+objs=()
+for s in "${srcs[@]}"; do
+  o="${here}/${s%.hip}.o"
+  if [[ ! -f "$o" || "$o" -ot "${here}/$s" || "$o" -ot "${here}/fvp_common.h" || "$o" -ot "${here}/fvp_geom.h" \
+        || "$o" -ot "${here}/../../include/fvp.h" ]]; then
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "${here}/$s" -o "$o" &
+  fi
+  objs+=("$o")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
+echo "built $out"

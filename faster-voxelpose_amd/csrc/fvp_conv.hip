@@ -1,0 +1,392 @@
+// Conv stacks on the fp32 matrix cores (gfx950): CenterNet / C2CNet / P2PNet.
+// Reference sites: lib/models/cnns_2d.py:12-178, lib/models/cnns_1d.py:10-132.
+//
+// Every conv is an implicit GEMM  D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],
+// k = (cin, ky, kx), on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain):
+//   A operand = weights  (row i = cout,  lane l holds A[l&31][k = l>>5])
+//   B operand = pixels   (col j = pixel, lane l holds B[k = l>>5][l&31])
+//   D         : lane l holds pixel column l&31 and cout rows (r&3) + 8*(r>>2) + 4*(l>>5)
+// so for a fixed accumulator register 32 lanes store 32 consecutive pixels of one output
+// channel: activations stay NCHW ([planes][C][H][W], the reference layout) end to end and
+// both global loads and stores are contiguous rows.
+//
+// Workgroup = 4 waves.  Tile = TN planes x TH rows x TW cols = 128*PB pixels x all couts
+// (coutp = 32*CB); wave w owns pixel blocks [w*PB, (w+1)*PB).  Per chunk of CC input
+// channels the workgroup stages
+//   Xs[CC][TN][TH+KH-1][TW+KW-1]   zero-padded halo tile (planar per channel => lanes of a
+//                                  pixel block read consecutive LDS words, conflict-free)
+//   Ws[CC][KH*KW][coutp]           a contiguous slice of the packed weights
+// and runs (CC/2)*KH*KW*CB*PB MFMAs per wave with one LDS word per operand.
+// BatchNorm (eval), bias, residual add and ReLU are fused into the store epilogue.
+#include <hip/hip_runtime.h>
+
+#include "fvp_common.h"
+
+namespace fvp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* src;
+  float* dst;
+  const float* res;
+  const float* wts;   // packed [cinp][KK][coutp] (+ tap-major blocks for transposed conv)
+  const float* epi;   // bias | scale | shift, each coutp
+  const uint8_t* plane_valid;
+  int valid_div;
+  int planes, cin, cinp, cout, coutp;
+  int H, W;           // input spatial size
+  int OH, OW;         // output spatial size
+  int osy, osx;       // output stride (2 for transposed conv, else 1)
+  int TN, TH, TW;     // tile
+  int tiles_x, tiles_y;
+  int CC;             // input channels per LDS chunk (even)
+  int flags;
+  int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
+  int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
+};
+
+template <int KH, int KW, int CB, int PB>
+__global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  constexpr int KK = KH * KW;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int THp = a.TH + KH - 1, TWp = a.TW + KW - 1;
+  const int plane_sz = THp * TWp;            // one channel of one plane in LDS
+  const int CS = a.TN * plane_sz;            // channel stride in Xs
+  float* Xs = smem;
+  float* Ws = smem + ((a.CC * CS + 3) & ~3);   // keep the weight slice 16-byte aligned
+
+  int tile = blockIdx.x;
+  const int tx_i = tile % a.tiles_x;
+  tile /= a.tiles_x;
+  const int ty_i = tile % a.tiles_y;
+  const int pg = tile / a.tiles_y;
+  const int plane0 = pg * a.TN;
+  const int y0 = ty_i * a.TH, x0 = tx_i * a.TW;
+  if (a.plane_valid && a.TN == 1 && !a.plane_valid[plane0 / a.valid_div]) return;
+
+  const int tapT = blockIdx.z;               // transposed-conv tap (0 otherwise)
+  const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp;
+
+  // per-lane LDS offset of each of this wave's pixels (B operand), -1 = masked
+  const int tile_px = a.TN * a.TH * a.TW;
+  int poff[PB];
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int q = (wave * PB + pb) * 32 + l31;
+    if (q < tile_px) {
+      const int n = q / (a.TH * a.TW), r = q - n * (a.TH * a.TW);
+      const int ty = r / a.TW, tx = r - ty * a.TW;
+      poff[pb] = n * plane_sz + ty * TWp + tx;
+    } else {
+      poff[pb] = 0;                          // reads valid LDS, result never stored
+    }
+  }
+
+  f32x16 acc[CB][PB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.0f;
+
+  const int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
+  const int HW = a.H * a.W;
+  const int nrows = a.CC * a.TN * THp;
+
+  for (int c0 = 0; c0 < a.cinp; c0 += a.CC) {
+    __syncthreads();
+    // ---- stage the halo tile: one (channel, plane, row) per wave iteration, lanes along x
+    for (int row = wave; row < nrows; row += 4) {
+      const int ci = row / (a.TN * THp);
+      const int rem = row - ci * (a.TN * THp);
+      const int n = rem / THp, ry = rem - n * THp;
+      const int c = c0 + ci, plane = plane0 + n, y = y0 + ry - padH;
+      const bool row_ok = c < a.cin && plane < a.planes && y >= 0 && y < a.H;
+      const float* g = row_ok ? a.src + (size_t(plane) * a.cin + c) * HW + size_t(y) * a.W : a.src;
+      float* d = Xs + ci * CS + n * plane_sz + ry * TWp;
+      for (int col = lane; col < TWp; col += 64) {
+        const int x = x0 + col - padW;
+        d[col] = (row_ok && x >= 0 && x < a.W) ? g[x] : 0.0f;
+      }
+    }
+    // ---- stage the weight slice (contiguous in the packed layout; zero beyond cinp)
+    {
+      const int nw = a.CC * KK * a.coutp;
+      const int avail = (a.cinp - c0) * KK * a.coutp;
+      const float* gw = wts + size_t(c0) * KK * a.coutp;
+      for (int e = t * 4; e < nw; e += 1024) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < avail) v = *reinterpret_cast<const float4*>(gw + e);
+        *reinterpret_cast<float4*>(Ws + e) = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the chunk
+    for (int ci = 0; ci < a.CC; ci += 2) {
+      const float* xs = Xs + (ci + half) * CS;
+      const float* ws = Ws + (ci + half) * KK * a.coutp + l31;
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          float av[CB], bv[PB];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) av[cb] = ws[(ky * KW + kx) * a.coutp + cb * 32];
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) bv[pb] = xs[poff[pb] + ky * TWp + kx];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, BN scale/shift, residual, ReLU; coalesced NCHW stores
+  const float* bias = a.epi;
+  const float* scale = a.epi + a.coutp;
+  const float* shift = a.epi + 2 * a.coutp;
+  const int OHW = a.OH * a.OW;
+  const int dy = (a.ntapT > 1) ? tapT / a.tapT_w : 0, dx = (a.ntapT > 1) ? tapT % a.tapT_w : 0;
+  const bool relu = a.flags & FVP_EPI_RELU, has_res = a.flags & FVP_EPI_RES;
+  const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int q = (wave * PB + pb) * 32 + l31;
+    if (q >= tile_px) continue;
+    const int n = q / (a.TH * a.TW), r2 = q - n * (a.TH * a.TW);
+    const int ty = r2 / a.TW, tx = r2 - ty * a.TW;
+    const int plane = plane0 + n, y = y0 + ty, x = x0 + tx;
+    if (plane >= a.planes || y >= a.H || x >= a.W) continue;
+    const size_t opix = size_t(y * a.osy + dy) * a.OW + (x * a.osx + dx);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a.cout) {
+          float v = acc[cb][pb][r] + bias[co];
+          v = v * scale[co] + shift[co];
+          const size_t o = (size_t(plane) * a.cout + co) * OHW + opix;
+          if (has_res && !res_after) v += a.res[o];
+          if (relu) v = fmaxf(v, 0.0f);
+          if (has_res && res_after) v += a.res[o];
+          a.dst[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// max_pool(2,2) / max_pool1d(2): one thread per output element.
+__global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ src, float* __restrict__ dst, long total,
+                                               int H, int W, const uint8_t* __restrict__ plane_valid, int valid_div,
+                                               int C) {
+  const long i = long(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int OW = W / 2, OH = H > 1 ? H / 2 : 1;
+  const int ox = int(i % OW);
+  const int oy = int((i / OW) % OH);
+  const long pc = i / (long(OW) * OH);
+  if (plane_valid && !plane_valid[(pc / C) / valid_div]) return;
+  const float* s = src + pc * long(H) * W + long(oy) * (H > 1 ? 2 : 1) * W + ox * 2;
+  float m = fmaxf(s[0], s[1]);
+  if (H > 1) m = fmaxf(m, fmaxf(s[W], s[W + 1]));
+  dst[i] = m;
+}
+
+// state_dict tensors -> packed [tapT][cinp][KK][coutp] + bias|scale|shift.
+__global__ void __launch_bounds__(256)
+k_pack_conv(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+            const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
+            int transposed, int cin, int cout, int cinp, int coutp, int kh, int kw, float* __restrict__ wdst,
+            float* __restrict__ edst) {
+  const int KK = kh * kw;
+  const int ntap = transposed ? KK : 1, kk = transposed ? 1 : KK;
+  const int nw = ntap * cinp * kk * coutp;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nw) {
+    const int co = i % coutp;
+    int r = i / coutp;
+    const int tap = r % kk;
+    r /= kk;
+    const int ci = r % cinp, tt = r / cinp;
+    float v = 0.0f;
+    if (co < cout && ci < cin) {
+      // Conv: weight[co][ci][ky][kx];  ConvTranspose: weight[ci][co][dy][dx]
+      v = transposed ? w[(size_t(ci) * cout + co) * KK + tt] : w[(size_t(co) * cin + ci) * KK + tap];
+    }
+    wdst[i] = v;
+  }
+  if (i < coutp) {
+    float bb = 0.0f, sc = 1.0f, sh = 0.0f;
+    if (i < cout) {
+      bb = b ? b[i] : 0.0f;
+      if (gamma) {
+        // eval BatchNorm: y = x * alpha + (beta - mean * alpha), alpha = gamma / sqrt(var + eps)
+        sc = __fdiv_rn(gamma[i], sqrtf(__fadd_rn(var[i], eps)));
+        sh = __fsub_rn(beta[i], __fmul_rn(mean[i], sc));
+      }
+    }
+    edst[i] = bb;
+    edst[coutp + i] = sc;
+    edst[2 * coutp + i] = sh;
+  }
+}
+
+template <int KH, int KW, int CB, int PB>
+static int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto k = &k_conv<KH, KW, CB, PB>;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  return launch_status();
+}
+
+template <int KH, int KW>
+static int dispatch_tile(int CB, int PB, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  const int key = CB * 10 + PB;
+  switch (key) {
+    case 11: return launch_conv<KH, KW, 1, 1>(a, grid, lds, s);
+    case 12: return launch_conv<KH, KW, 1, 2>(a, grid, lds, s);
+    case 14: return launch_conv<KH, KW, 1, 4>(a, grid, lds, s);
+    case 21: return launch_conv<KH, KW, 2, 1>(a, grid, lds, s);
+    case 22: return launch_conv<KH, KW, 2, 2>(a, grid, lds, s);
+    case 24: return launch_conv<KH, KW, 2, 4>(a, grid, lds, s);
+    case 41: return launch_conv<KH, KW, 4, 1>(a, grid, lds, s);
+    case 42: return launch_conv<KH, KW, 4, 2>(a, grid, lds, s);
+    default: return FVP_ELIMIT;
+  }
+}
+
+static int dispatch_conv(int kh, int kw, int CB, int PB, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (kh == 7 && kw == 7) return dispatch_tile<7, 7>(CB, PB, a, grid, lds, s);
+  if (kh == 3 && kw == 3) return dispatch_tile<3, 3>(CB, PB, a, grid, lds, s);
+  if (kh == 1 && kw == 1) return dispatch_tile<1, 1>(CB, PB, a, grid, lds, s);
+  if (kh == 1 && kw == 7) return dispatch_tile<1, 7>(CB, PB, a, grid, lds, s);
+  if (kh == 1 && kw == 3) return dispatch_tile<1, 3>(CB, PB, a, grid, lds, s);
+  return FVP_ELIMIT;
+}
+
+static constexpr size_t kLdsBudget = 64 * 1024;
+
+// Tile selection: all couts per workgroup (CB = coutp/32), PB so that CB*PB <= 8 accumulator
+// tiles per wave, the tile shaped to cover full image rows where possible.
+static int plan_and_launch(const FvpConvOp& op, const float* params, float* const* bufs, int planes,
+                           const uint8_t* plane_valid, int valid_div, hipStream_t s) {
+  ConvArgs a{};
+  const bool tr = op.kind == FVP_OP_CONVT2;
+  const int kh = tr ? 1 : op.kh, kw = tr ? 1 : op.kw;
+  a.src = bufs[op.src];
+  a.dst = bufs[op.dst];
+  a.res = op.res >= 0 ? bufs[op.res] : nullptr;
+  a.wts = params + op.w_off;
+  a.epi = params + op.e_off;
+  a.plane_valid = plane_valid;
+  a.valid_div = valid_div > 0 ? valid_div : 1;
+  a.planes = planes;
+  a.cin = op.cin;
+  a.cinp = op.cinp;
+  a.cout = op.cout;
+  a.coutp = op.coutp;
+  a.H = op.h;
+  a.W = op.w;
+  a.flags = op.flags;
+  if (tr) {
+    a.osx = 2;
+    a.osy = op.h > 1 ? 2 : 1;
+    a.ntapT = op.h > 1 ? 4 : 2;
+    a.tapT_w = 2;
+  } else {
+    a.osx = a.osy = 1;
+    a.ntapT = 1;
+    a.tapT_w = 1;
+  }
+  a.OH = op.h * a.osy;
+  a.OW = op.w * a.osx;
+  const int CB = op.coutp / 32;
+  if (CB != 1 && CB != 2 && CB != 4) return FVP_ELIMIT;
+  // pixels per plane decide PB (PB*128 pixels per workgroup)
+  const int hw = op.h * op.w;
+  int PB = CB == 1 ? 4 : (CB == 2 ? 4 : 2);
+  while (PB > 1 && PB * 128 > hw * (planes > 0 ? planes : 1)) PB >>= 1;
+  if (hw * planes < 128) PB = 1;
+  const int TP = PB * 128;
+  if (hw <= TP) {                       // whole planes per tile
+    a.TW = op.w;
+    a.TH = op.h;
+    a.TN = TP / hw > 0 ? TP / hw : 1;
+  } else if (op.w <= TP) {              // full-width row bands
+    a.TW = op.w;
+    a.TH = TP / op.w;
+    a.TN = 1;
+  } else {
+    a.TW = TP;
+    a.TH = 1;
+    a.TN = 1;
+  }
+  a.tiles_x = ceil_div(op.w, a.TW);
+  a.tiles_y = ceil_div(op.h, a.TH);
+  const int pgroups = ceil_div(planes, a.TN);
+  // channel chunk: largest even CC that fits the LDS budget
+  const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * (a.TW + kw - 1) + size_t(kh) * kw * op.coutp) * sizeof(float);
+  int CC = int((kLdsBudget - 16) / per_ch) & ~1;
+  if (CC > op.cinp) CC = op.cinp;
+  if (CC < 2) return FVP_ELIMIT;
+  a.CC = CC;
+  const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * (a.TW + kw - 1) + 3) & ~size_t(3);
+  const size_t lds = (xs_floats + size_t(CC) * kh * kw * op.coutp) * sizeof(float);
+  dim3 grid(a.tiles_x * a.tiles_y * pgroups, 1, a.ntapT);
+  // algorithmic FLOPs (2*MAC on the true channel counts)
+  const double taps = tr ? double(a.ntapT) : double(op.kh * op.kw);
+  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * hw * planes);
+  return dispatch_conv(kh, kw, CB, PB, a, grid, lds, s);
+}
+
+}  // namespace fvp
+
+using namespace fvp;
+
+extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* params, float* const* bufs, int nbufs,
+                                  int planes, const uint8_t* plane_valid, int valid_div, fvp_stream_t s) {
+  FVP_REQUIRE(ops && params && bufs && nops >= 0 && planes >= 0);
+  if (planes == 0) return 0;
+  for (int i = 0; i < nops; ++i) {
+    const FvpConvOp& op = ops[i];
+    FVP_REQUIRE(op.src >= 0 && op.src < nbufs && op.dst >= 0 && op.dst < nbufs && op.res < nbufs);
+    int rc;
+    if (op.kind == FVP_OP_POOL2) {
+      FVP_REQUIRE(op.w % 2 == 0 && (op.h == 1 || op.h % 2 == 0));
+      const long total = long(planes) * op.cin * (op.h > 1 ? op.h / 2 : 1) * (op.w / 2);
+      ProfScope ps(FVP_K_OTHER, as_stream(s));
+      hipLaunchKernelGGL(k_pool2, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(s),
+                         (const float*)bufs[op.src], bufs[op.dst], total, op.h, op.w, plane_valid,
+                         valid_div > 0 ? valid_div : 1, op.cin);
+      rc = launch_status();
+    } else if (op.kind == FVP_OP_CONV || op.kind == FVP_OP_CONVT2) {
+      rc = plan_and_launch(op, params, bufs, planes, plane_valid, valid_div, as_stream(s));
+    } else {
+      rc = FVP_EINVAL;
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int fvp_pack_conv(const float* weight, const float* bias, const float* bn_gamma, const float* bn_beta,
+                             const float* bn_mean, const float* bn_var, float eps, int transposed,
+                             const FvpConvOp* op, float* params, fvp_stream_t s) {
+  FVP_REQUIRE(weight && op && params);
+  FVP_REQUIRE(!bn_gamma || (bn_beta && bn_mean && bn_var));
+  const int KK = op->kh * op->kw;
+  const int nw = op->cinp * KK * op->coutp;
+  const int n = nw > op->coutp ? nw : op->coutp;
+  hipLaunchKernelGGL(k_pack_conv, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(s), weight, bias, bn_gamma,
+                     bn_beta, bn_mean, bn_var, eps, transposed, op->cin, op->cout, op->cinp, op->coutp, op->kh,
+                     op->kw, params + op->w_off, params + op->e_off);
+  return launch_status();
+}

@@ -1,0 +1,493 @@
+// Back-projection kernels (gfx950): heatmap staging, sampling grids, whole-space cubes with
+// fused z-max, per-person cubes, orthographic tri-plane maxima, and the fused
+// project+tri-plane fast path.  Reference sites: lib/models/project_whole.py:49-88,
+// lib/models/project_individual.py:60-136, lib/models/joint_localization_net.py:80-81,
+// lib/models/cnns_2d.py:174.
+//
+// Data layout in HBM
+//   heat     [B][V][J][H][W]        NCHW, as the reference hands it over
+//   heat_cl  [B][V][H*W][JP]        channels-last, JP = 4*ceil(J/4): one bilinear tap of one
+//                                   (voxel, view) is JP contiguous floats = JP/4 dwordx4 loads
+//                                   shared by all joints (the reference gathers J planes)
+//   cubes    [B][J][X][Y][Z]        z fastest (reference layout)
+//   planes   [nP][3][J][C][C]       xy | xz | yz maxima of one person's cube
+// All kernels are HBM/L2-bound gathers; lanes run along z so loads of neighbouring voxels hit
+// neighbouring heatmap pixels and every store is a contiguous 256-byte row.
+#include <hip/hip_runtime.h>
+
+#include "fvp_common.h"
+#include "fvp_geom.h"
+
+namespace fvp {
+
+// ---------------------------------------------------------------------------------------------
+// NCHW -> channels-last staging: one thread per pixel, coalesced reads per channel plane,
+// JP/4 dwordx4 stores per thread.
+template <int NV>
+__global__ void __launch_bounds__(256) k_heat_to_cl(const float* __restrict__ heat, float* __restrict__ cl,
+                                                    int J, int HW) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const size_t bv = blockIdx.y;
+  if (pix >= HW) return;
+  const float* src = heat + bv * size_t(J) * HW + pix;
+  float v[4 * NV];
+#pragma unroll
+  for (int j = 0; j < 4 * NV; ++j) v[j] = (j < J) ? src[size_t(j) * HW] : 0.0f;
+  float4* dst = reinterpret_cast<float4*>(cl + (bv * HW + pix) * size_t(4 * NV));
+#pragma unroll
+  for (int q = 0; q < NV; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampling grid for the drop-in cache / parity tests: one thread per (view, voxel).
+__global__ void __launch_bounds__(256) k_sample_grid(const float* __restrict__ ax, const float* __restrict__ ay,
+                                                     const float* __restrict__ az, int nx, int ny, int nz,
+                                                     const Cam* __restrict__ cams, FvpGeom g,
+                                                     float* __restrict__ grid) {
+  const int n = nx * ny * nz;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int v = blockIdx.y;
+  if (i >= n) return;
+  const int iz = i % nz, iy = (i / nz) % ny, ix = i / (nz * ny);
+  float gx, gy;
+  project_norm(cams[v], g, ax[ix], ay[iy], az[iz], gx, gy);
+  grid[(size_t(v) * n + i) * 2 + 0] = gx;
+  grid[(size_t(v) * n + i) * 2 + 1] = gy;
+}
+
+// mean over views of the bilinear samples of one world point, clamped to [0,1]
+// (project_whole.py:83,86 / project_individual.py:130,134): sum views in order, divide by V.
+template <int NV>
+__device__ __forceinline__ void backproject_point(const float* __restrict__ heat_cl_frame,
+                                                  const Cam* __restrict__ cams, const FvpGeom& g, float wx,
+                                                  float wy, float wz, float (&acc)[4 * NV]) {
+  const size_t view_stride = size_t(g.H) * g.W * (4 * NV);
+  for (int v = 0; v < g.V; ++v) {
+    float gx, gy;
+    project_norm(cams[v], g, wx, wy, wz, gx, gy);
+    const Taps t = bilinear_taps(gx, gy, g.W, g.H);
+    float s[4 * NV];
+    if (t.inside) {
+      sample_view<NV>(heat_cl_frame + v * view_stride, t, s);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4 * NV; ++c) s[c] = 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4 * NV; ++c) acc[c] = (v == 0) ? s[c] : __fadd_rn(acc[c], s[c]);
+  }
+  const float nv = float(g.V);
+#pragma unroll
+  for (int c = 0; c < 4 * NV; ++c) acc[c] = clampf(__fdiv_rn(acc[c], nv), 0.0f, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-space cubes (+ fused z-max).  A workgroup owns CPB = 256/Z complete z-columns so the
+// z-max never leaves the workgroup: values go through LDS [JP][256] and CPB*J threads each
+// reduce one column of one joint.
+template <int NV>
+__global__ void __launch_bounds__(256)
+k_project_whole(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
+                const float* __restrict__ ax, const float* __restrict__ ay, const float* __restrict__ az, int X,
+                int Y, int Z, FvpGeom g, float* __restrict__ cubes, float* __restrict__ zmax) {
+  __shared__ float sm[4 * NV][256];
+  const int cpb = 256 / Z;
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int cl_ = t / Z, z = t - cl_ * Z;
+  const int col = blockIdx.x * cpb + cl_;
+  const int ncol = X * Y;
+  const bool active = cl_ < cpb && col < ncol;
+  const int J = g.J;
+  float acc[4 * NV];
+#pragma unroll
+  for (int c = 0; c < 4 * NV; ++c) acc[c] = 0.0f;
+  if (active) {
+    const int x = col / Y, y = col - x * Y;
+    const float* frame = heat_cl + size_t(b) * g.V * g.H * g.W * (4 * NV);
+    backproject_point<NV>(frame, cams + size_t(frame_set[b]) * g.V, g, ax[x], ay[y], az[z], acc);
+    if (cubes) {
+      const size_t vox = size_t(col) * Z + z;
+      const size_t nvox = size_t(ncol) * Z;
+#pragma unroll
+      for (int c = 0; c < 4 * NV; ++c)
+        if (c < J) cubes[(size_t(b) * J + c) * nvox + vox] = acc[c];
+    }
+  }
+  if (zmax) {
+#pragma unroll
+    for (int c = 0; c < 4 * NV; ++c) sm[c][t] = acc[c];
+    __syncthreads();
+    for (int item = t; item < cpb * J; item += 256) {
+      const int c = item / cpb, k = item - c * cpb;
+      const int cc = blockIdx.x * cpb + k;
+      if (cc < ncol) {
+        float m = sm[c][k * Z];
+        for (int zz = 1; zz < Z; ++zz) m = fmaxf(m, sm[c][k * Z + zz]);
+        zmax[(size_t(b) * J + c) * ncol + cc] = m;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-person cube, materialised (drop-in for project_individual.ProjectLayer.forward).
+// boxes[p] = tl[3], start[3], end[3] in fine-grid indices (fvp_person_boxes).
+template <int NV>
+__global__ void __launch_bounds__(256)
+k_project_individual(const float* __restrict__ heat_cl, const Cam* __restrict__ cams,
+                     const int* __restrict__ frame_set, const int* __restrict__ person_frame,
+                     const uint8_t* __restrict__ person_valid, const int* __restrict__ boxes,
+                     const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ fz, int C,
+                     FvpGeom g, float* __restrict__ cubes) {
+  const int p = blockIdx.y;
+  const int lv = blockIdx.x * 256 + threadIdx.x;
+  const int nvox = C * C * C;
+  if (lv >= nvox) return;
+  const int J = g.J;
+  const int lz = lv % C, ly = (lv / C) % C, lx = lv / (C * C);
+  const int* bx = boxes + p * 9;
+  const int gx_ = bx[0] + lx, gy_ = bx[1] + ly, gz_ = bx[2] + lz;
+  bool in = (!person_valid || person_valid[p]);
+  in = in && bx[3] < bx[6] && bx[4] < bx[7] && bx[5] < bx[8];   // empty window -> all zero (:125)
+  in = in && gx_ >= bx[3] && gx_ < bx[6] && gy_ >= bx[4] && gy_ < bx[7] && gz_ >= bx[5] && gz_ < bx[8];
+  float acc[4 * NV];
+#pragma unroll
+  for (int c = 0; c < 4 * NV; ++c) acc[c] = 0.0f;
+  if (in) {
+    const int b = person_frame[p];
+    const float* frame = heat_cl + size_t(b) * g.V * g.H * g.W * (4 * NV);
+    backproject_point<NV>(frame, cams + size_t(frame_set[b]) * g.V, g, fx[gx_], fy[gy_], fz[gz_], acc);
+  }
+#pragma unroll
+  for (int c = 0; c < 4 * NV; ++c)
+    if (c < J) cubes[(size_t(p) * J + c) * nvox + lv] = acc[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Orthographic maxima of a materialised cube: one workgroup per (person, joint), x-slabs
+// streamed through LDS; yz keeps a running max in registers.
+__global__ void __launch_bounds__(256)
+k_triplane_max(const float* __restrict__ cubes, float* __restrict__ planes, int J, int C) {
+  HIP_DYNAMIC_SHARED(float, slab)                     // [C][C+1]
+  const int j = blockIdx.x, p = blockIdx.y, t = threadIdx.x;
+  const int CC = C * C, ld = C + 1;
+  const float* cube = cubes + (size_t(p) * J + j) * CC * C;
+  float* pxy = planes + ((size_t(p) * 3 + 0) * J + j) * CC;
+  float* pxz = planes + ((size_t(p) * 3 + 1) * J + j) * CC;
+  float* pyz = planes + ((size_t(p) * 3 + 2) * J + j) * CC;
+  const int per = (CC + 255) / 256;                   // (y,z) cells per thread, <= 64 for C <= 128
+  float run[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) run[i] = -INFINITY;
+  for (int x = 0; x < C; ++x) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i < per) {
+        const int cell = t + i * 256;
+        if (cell < CC) {
+          const float v = cube[size_t(x) * CC + cell];
+          slab[(cell / C) * ld + (cell % C)] = v;
+          run[i] = fmaxf(run[i], v);
+        }
+      }
+    }
+    __syncthreads();
+    for (int r = t; r < 2 * C; r += 256) {
+      if (r < C) {                                     // xy[x][y=r] = max_z
+        float m = slab[r * ld];
+        for (int z = 1; z < C; ++z) m = fmaxf(m, slab[r * ld + z]);
+        pxy[x * C + r] = m;
+      } else {                                         // xz[x][z] = max_y
+        const int z = r - C;
+        float m = slab[z];
+        for (int y = 1; y < C; ++y) m = fmaxf(m, slab[y * ld + z]);
+        pxz[x * C + z] = m;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    if (i < per) {
+      const int cell = t + i * 256;
+      if (cell < CC) pyz[cell] = run[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused fast path: sample every voxel of the person's window and emit the three maxima
+// without writing the cube.  Workgroup = (person, chunk of 256/C rows of y); thread = one
+// (y,z) cell, lanes along z; loop over x.
+//   yz[y][z] = max_x : running max in registers, owned by this workgroup -> plain store
+//   xy[x][y] = max_z : segmented wave-shuffle reduction over the row's lanes
+//   xz[x][z] = max_y : LDS reduction over the workgroup's rows, then integer atomicMax across
+//                      workgroups (values are clamped to [0,1] => non-negative => the int
+//                      ordering equals the float ordering; planes are pre-zeroed)
+template <int NV>
+__global__ void __launch_bounds__(256)
+k_project_triplane(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
+                   const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
+                   const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
+                   const float* __restrict__ fz, int C, FvpGeom g, float* __restrict__ planes) {
+  __shared__ float sm[4 * NV][256];
+  const int p = blockIdx.y;
+  if (person_valid && !person_valid[p]) return;
+  const int* bx = boxes + p * 9;
+  const int tl0 = bx[0], tl1 = bx[1], tl2 = bx[2];
+  const int s0 = bx[3], s1 = bx[4], s2 = bx[5], e0 = bx[6], e1 = bx[7], e2 = bx[8];
+  if (s0 >= e0 || s1 >= e1 || s2 >= e2) return;
+  const int t = threadIdx.x, J = g.J, CC = C * C;
+  const int rows = 256 / C > 0 ? 256 / C : 1;           // y rows per workgroup (C <= 256)
+  const int seg = C < 64 ? C : 64;                      // lanes sharing one (x,y) row in a wave
+  const int cell = blockIdx.x * 256 + t;                // (y,z) cell of this thread
+  const int y = cell / C, z = cell - y * C;
+  const int y_first = (blockIdx.x * 256) / C;
+  // whole chunk outside the y window -> nothing to do (planes are pre-zeroed)
+  if (tl1 + y_first >= e1 || tl1 + y_first + rows - 1 < s1) return;
+  const int gy_ = tl1 + y, gz_ = tl2 + z;
+  const bool yz_in = gy_ >= s1 && gy_ < e1 && gz_ >= s2 && gz_ < e2;
+  const int b = person_frame[p];
+  const float* frame = heat_cl + size_t(b) * g.V * g.H * g.W * (4 * NV);
+  const Cam* cm = cams + size_t(frame_set[b]) * g.V;
+  const float wy = yz_in ? fy[gy_] : 0.0f, wz = yz_in ? fz[gz_] : 0.0f;
+  float* pxy = planes + (size_t(p) * 3 + 0) * J * CC;
+  float* pxz = planes + (size_t(p) * 3 + 1) * J * CC;
+  float* pyz = planes + (size_t(p) * 3 + 2) * J * CC;
+  float run[4 * NV];
+#pragma unroll
+  for (int c = 0; c < 4 * NV; ++c) run[c] = 0.0f;
+  const int lx0 = s0 - tl0, lx1 = e0 - tl0;
+  for (int lx = lx0; lx < lx1; ++lx) {
+    float acc[4 * NV];
+#pragma unroll
+    for (int c = 0; c < 4 * NV; ++c) acc[c] = 0.0f;
+    if (yz_in) backproject_point<NV>(frame, cm, g, fx[tl0 + lx], wy, wz, acc);
+#pragma unroll
+    for (int c = 0; c < 4 * NV; ++c) run[c] = fmaxf(run[c], acc[c]);
+    // xy: max over z within the row segment
+#pragma unroll
+    for (int c = 0; c < 4 * NV; ++c) {
+      float m = acc[c];
+      for (int o = seg >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if (c < J && (t & (seg - 1)) == 0 && m > 0.0f) {
+        if (C <= 64) pxy[size_t(c) * CC + lx * C + y] = m;
+        else atomicMax(reinterpret_cast<int*>(&pxy[size_t(c) * CC + lx * C + y]), __float_as_int(m));
+      }
+    }
+    // xz: max over this workgroup's rows through LDS, then across workgroups
+    if (rows > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 4 * NV; ++c) sm[c][t] = acc[c];
+      __syncthreads();
+      for (int item = t; item < J * C; item += 256) {
+        const int c = item / C, zz = item - c * C;
+        float m = sm[c][zz];
+        for (int r = 1; r < rows; ++r) m = fmaxf(m, sm[c][r * C + zz]);
+        if (m > 0.0f) atomicMax(reinterpret_cast<int*>(&pxz[size_t(c) * CC + lx * C + zz]), __float_as_int(m));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4 * NV; ++c)
+        if (c < J && acc[c] > 0.0f)
+          atomicMax(reinterpret_cast<int*>(&pxz[size_t(c) * CC + lx * C + z]), __float_as_int(acc[c]));
+    }
+  }
+  if (y < C) {
+#pragma unroll
+    for (int c = 0; c < 4 * NV; ++c)
+      if (c < J && run[c] > 0.0f) pyz[size_t(c) * CC + y * C + z] = run[c];
+  }
+}
+
+// z-max of materialised cubes: one thread per (b,j,x,y) column.
+__global__ void __launch_bounds__(256) k_zmax(const float* __restrict__ cubes, float* __restrict__ zmax, long n, int Z) {
+  const long i = long(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* c = cubes + i * Z;
+  float m = c[0];
+  for (int z = 1; z < Z; ++z) m = fmaxf(m, c[z]);
+  zmax[i] = m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fvp_person_boxes: integer window arithmetic of project_individual.py:110-121.
+__global__ void __launch_bounds__(64)
+k_person_boxes(const float* __restrict__ centers, int n, const float* __restrict__ consts, int f0, int f1, int f2,
+               int c0, int c1, int c2, int* __restrict__ boxes, float* __restrict__ offset) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const float* pc = centers + size_t(i) * 7;
+  const int fine[3] = {f0, f1, f2}, cube[3] = {c0, c1, c2};
+  int tl[3], m[3];
+  for (int a = 0; a < 3; ++a) {
+    // round(c*scale + bias): two roundings then half-to-even, .int() truncation (exact here)
+    const float v = __fadd_rn(__fmul_rn(pc[a], consts[a]), consts[3 + a]);
+    tl[a] = int(rintf(v));
+    // offset = tl / (fine-1) * whole - whole/2 + ind/2   (left to right, :111)
+    const float whole = consts[6 + a], ind = consts[9 + a];
+    float o = __fmul_rn(__fdiv_rn(float(tl[a]), float(fine[a] - 1)), whole);
+    o = __fadd_rn(__fsub_rn(o, __fdiv_rn(whole, 2.0f)), __fdiv_rn(ind, 2.0f));
+    offset[size_t(i) * 3 + a] = o;
+  }
+  for (int a = 0; a < 2; ++a) {
+    // ((1 - bbox) / 2 * (C - 1)).int(), negatives -> 0 (:114-115); z margin is 0 (:117)
+    const float r = __fmul_rn(__fdiv_rn(__fsub_rn(1.0f, pc[5 + a]), 2.0f), float(cube[a] - 1));
+    m[a] = int(r);
+    if (m[a] < 0) m[a] = 0;
+  }
+  m[2] = 0;
+  for (int a = 0; a < 3; ++a) {
+    const int s = tl[a] + m[a], e = tl[a] + cube[a] - m[a];
+    boxes[i * 9 + a] = tl[a];
+    boxes[i * 9 + 3 + a] = s >= 0 ? s : 0;
+    boxes[i * 9 + 6 + a] = e <= fine[a] ? e : fine[a];
+  }
+}
+
+}  // namespace fvp
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace fvp;
+
+#define FVP_NV_SWITCH(nv, CALL)     \
+  switch (nv) {                     \
+    case 1: { CALL(1); } break;     \
+    case 2: { CALL(2); } break;     \
+    case 3: { CALL(3); } break;     \
+    case 4: { CALL(4); } break;     \
+    case 5: { CALL(5); } break;     \
+    case 6: { CALL(6); } break;     \
+    case 7: { CALL(7); } break;     \
+    case 8: { CALL(8); } break;     \
+    default: return FVP_ELIMIT;     \
+  }
+
+static int check_geom(const FvpGeom* g) {
+  if (!g) return FVP_EINVAL;
+  if (g->V < 1 || g->V > FVP_MAX_VIEWS || g->J < 1 || g->J > FVP_MAX_JOINTS) return FVP_ELIMIT;
+  if (g->JP != 4 * ((g->J + 3) / 4) || g->W < 2 || g->H < 2) return FVP_EINVAL;
+  return 0;
+}
+
+extern "C" int fvp_heatmaps_to_cl(const float* heat, float* heat_cl, int B, const FvpGeom* g, fvp_stream_t s) {
+  FVP_REQUIRE(heat && heat_cl && B >= 0);
+  if (int e = check_geom(g)) return e;
+  if (B == 0) return 0;
+  const int HW = g->H * g->W;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+#define CALL(NV)                                                                                             \
+  auto k = &k_heat_to_cl<NV>;                                                                                \
+  hipLaunchKernelGGL(k, dim3(ceil_div(HW, 256), B * g->V), dim3(256), 0, as_stream(s), heat, heat_cl, g->J, HW);
+  FVP_NV_SWITCH(g->JP / 4, CALL)
+#undef CALL
+  return launch_status();
+}
+
+extern "C" int fvp_sample_grid(const float* ax, const float* ay, const float* az, int nx, int ny, int nz,
+                               const float* cams, const FvpGeom* g, float* grid, fvp_stream_t s) {
+  FVP_REQUIRE(ax && ay && az && cams && grid && nx > 0 && ny > 0 && nz > 0);
+  if (int e = check_geom(g)) return e;
+  const int n = nx * ny * nz;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+  hipLaunchKernelGGL(k_sample_grid, dim3(ceil_div(n, 256), g->V), dim3(256), 0, as_stream(s), ax, ay, az, nx, ny,
+                     nz, reinterpret_cast<const Cam*>(cams), *g, grid);
+  return launch_status();
+}
+
+extern "C" int fvp_project_whole(const float* heat_cl, const float* cams, const int32_t* frame_set,
+                                 const float* ax, const float* ay, const float* az, int X, int Y, int Z, int B,
+                                 const FvpGeom* g, float* cubes, float* zmax, fvp_stream_t s) {
+  FVP_REQUIRE(heat_cl && cams && frame_set && ax && ay && az && (cubes || zmax) && X > 0 && Y > 0 && Z > 0);
+  if (int e = check_geom(g)) return e;
+  FVP_LIMIT(Z <= 256);
+  if (B == 0) return 0;
+  const int cpb = 256 / Z;
+  ProfScope ps(FVP_K_PROJECT_WHOLE, as_stream(s));
+#define CALL(NV)                                                                                              \
+  auto k = &k_project_whole<NV>;                                                                              \
+  hipLaunchKernelGGL(k, dim3(ceil_div(X * Y, cpb), B), dim3(256), 0, as_stream(s), heat_cl,                   \
+                     reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, *g, cubes, zmax);
+  FVP_NV_SWITCH(g->JP / 4, CALL)
+#undef CALL
+  return launch_status();
+}
+
+extern "C" int fvp_zmax(const float* cubes, float* zmax, long n, int Z, fvp_stream_t s) {
+  FVP_REQUIRE(cubes && zmax && n >= 0 && Z > 0);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_zmax, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(s), cubes, zmax, n, Z);
+  return launch_status();
+}
+
+extern "C" int fvp_person_boxes(const float* centers, int n, const float* consts, const int32_t* fine_cube,
+                                int32_t* boxes, float* offset, fvp_stream_t s) {
+  FVP_REQUIRE(centers && consts && fine_cube && boxes && offset && n >= 0);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_person_boxes, dim3(ceil_div(n, 64)), dim3(64), 0, as_stream(s), centers, n, consts,
+                     fine_cube[0], fine_cube[1], fine_cube[2], fine_cube[3], fine_cube[4], fine_cube[5], boxes,
+                     offset);
+  return launch_status();
+}
+
+static int check_cube(int C) {
+  if (C < 4 || C > 256 || (C & (C - 1)) != 0) return FVP_ELIMIT;   // power of two (row segments)
+  return 0;
+}
+
+extern "C" int fvp_project_individual(const float* heat_cl, const float* cams, const int32_t* frame_set,
+                                      const int32_t* person_frame, const uint8_t* person_valid,
+                                      const int32_t* boxes, const float* fx, const float* fy, const float* fz,
+                                      const int32_t* fine, int C, int nP, const FvpGeom* g, float* cubes,
+                                      fvp_stream_t s) {
+  FVP_REQUIRE(heat_cl && cams && frame_set && person_frame && boxes && fx && fy && fz && cubes && nP >= 0);
+  (void)fine;
+  if (int e = check_geom(g)) return e;
+  if (int e = check_cube(C)) return e;
+  if (nP == 0) return 0;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+#define CALL(NV)                                                                                                 \
+  auto k = &k_project_individual<NV>;                                                                            \
+  hipLaunchKernelGGL(k, dim3(ceil_div(C * C * C, 256), nP), dim3(256), 0, as_stream(s), heat_cl,                 \
+                     reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, \
+                     C, *g, cubes);
+  FVP_NV_SWITCH(g->JP / 4, CALL)
+#undef CALL
+  return launch_status();
+}
+
+extern "C" int fvp_triplane_max(const float* cubes, float* planes, int nP, int J, int C, fvp_stream_t s) {
+  FVP_REQUIRE(cubes && planes && nP >= 0 && J > 0);
+  if (int e = check_cube(C)) return e;
+  FVP_LIMIT(C <= 128);
+  if (nP == 0) return 0;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+  hipLaunchKernelGGL(k_triplane_max, dim3(J, nP), dim3(256), size_t(C) * (C + 1) * sizeof(float), as_stream(s), cubes,
+                     planes, J, C);
+  return launch_status();
+}
+
+extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float* cams, const int32_t* frame_set,
+                                               const int32_t* person_frame, const uint8_t* person_valid,
+                                               const int32_t* boxes, const float* fx, const float* fy,
+                                               const float* fz, const int32_t* fine, int C, int nP, const FvpGeom* g,
+                                               float* planes, fvp_stream_t s) {
+  FVP_REQUIRE(heat_cl && cams && frame_set && person_frame && boxes && fx && fy && fz && planes && nP >= 0);
+  (void)fine;
+  if (int e = check_geom(g)) return e;
+  if (int e = check_cube(C)) return e;
+  if (nP == 0) return 0;
+  ProfScope ps(FVP_K_PROJECT_TRIPLANE, as_stream(s));
+#define CALL(NV)                                                                                                 \
+  auto k = &k_project_triplane<NV>;                                                                              \
+  hipLaunchKernelGGL(k, dim3(ceil_div(C * C, 256), nP), dim3(256), 0, as_stream(s), heat_cl,                     \
+                     reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, \
+                     C, *g, planes);
+  FVP_NV_SWITCH(g->JP / 4, CALL)
+#undef CALL
+  return launch_status();
+}

@@ -1,0 +1,161 @@
+// Proposal path (gfx950): 3x3 NMS + exact top-k, gathers at the selected cells, z arg-max and
+// proposal packing.  Integer / index results are bit-exact with the reference
+// (lib/core/proposal.py:13-33, lib/models/human_detection_net.py:44-65, :85-102).
+// Tie rule (torch.topk leaves ties unspecified): value descending, then lowest flat index.
+#include <hip/hip_runtime.h>
+
+#include "fvp_common.h"
+
+namespace fvp {
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
+  return v > bv || (v == bv && i < bi);
+}
+
+// One workgroup per frame.  LDS holds the NMS-ed map; N rounds of block arg-max.
+__global__ void __launch_bounds__(256)
+k_nms_topk(const float* __restrict__ hm, int X, int Y, int N, float* __restrict__ vals, long long* __restrict__ idx,
+           long long* __restrict__ flat) {
+  HIP_DYNAMIC_SHARED(float, kept)               // [X*Y] + 8 slots for the cross-wave stage
+  const int b = blockIdx.x, t = threadIdx.x, n = X * Y;
+  const float* m = hm + size_t(b) * n;
+  float* wv = kept + n;                         // [4] values
+  int* wi = reinterpret_cast<int*>(kept + n + 4);  // [4] indices
+  for (int i = t; i < n; i += 256) {
+    const int x = i / Y, y = i - x * Y;
+    const float c = m[i];
+    float mx = c;
+    for (int dx = -1; dx <= 1; ++dx)
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int xx = x + dx, yy = y + dy;
+        if (xx >= 0 && xx < X && yy >= 0 && yy < Y) mx = fmaxf(mx, m[xx * Y + yy]);
+      }
+    // keep = (x == max).float(); keep * x   (core/proposal.py:23-25)
+    kept[i] = __fmul_rn((c == mx) ? 1.0f : 0.0f, c);
+  }
+  __syncthreads();
+  for (int k = 0; k < N; ++k) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = t; i < n; i += 256) {
+      const float v = kept[i];
+      if (better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if ((t & 63) == 0) { wv[t >> 6] = bv; wi[t >> 6] = bi; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (better(wv[w], wi[w], bv, bi)) { bv = wv[w]; bi = wi[w]; }
+      if (bi == 0x7fffffff) bi = 0;             // N > number of finite cells: degenerate, pick cell 0
+      vals[size_t(b) * N + k] = bi < n ? kept[bi] : 0.0f;
+      flat[size_t(b) * N + k] = bi;
+      // the reference unravels with shape[1] = X for both coordinates (core/proposal.py:16-17)
+      idx[(size_t(b) * N + k) * 2 + 0] = bi / X;
+      idx[(size_t(b) * N + k) * 2 + 1] = bi % X;
+      if (bi < n) kept[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_gather(const float* __restrict__ bbox_map, const float* __restrict__ cubes, const long long* __restrict__ flat, int B,
+         int J, int XY, int Z, int N, float* __restrict__ bbox_flat, float* __restrict__ match_bbox,
+         float* __restrict__ feat1d) {
+  const long i = long(blockIdx.x) * 256 + threadIdx.x;
+  if (bbox_flat && i < long(B) * XY * 2) {      // [B][XY][2] <- [B][2][XY]
+    const int c = int(i % 2);
+    const long r = i / 2;
+    const int cell = int(r % XY), b = int(r / XY);
+    bbox_flat[i] = bbox_map[(size_t(b) * 2 + c) * XY + cell];
+  }
+  if (i < long(B) * N * 2) {
+    const int c = int(i % 2);
+    const long r = i / 2;
+    const int b = int(r / N);
+    match_bbox[i] = bbox_map[(size_t(b) * 2 + c) * XY + flat[r]];
+  }
+  if (i < long(B) * N * J * Z) {                // feat1d[b*N+k][j][z] = cubes[b][j][flat][z]
+    const int z = int(i % Z);
+    long r = i / Z;
+    const int j = int(r % J);
+    r /= J;
+    const int b = int(r / N);
+    feat1d[i] = cubes[((size_t(b) * J + j) * XY + flat[r]) * Z + z];
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_proposals(const float* __restrict__ hm1d, const float* __restrict__ conf2d, const long long* __restrict__ idx2d,
+            const float* __restrict__ match_bbox, const float* __restrict__ sb, float min_score, int BN, int Z,
+            long long* __restrict__ topk_index, float* __restrict__ centers) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= BN) return;
+  const float* h = hm1d + size_t(i) * Z;
+  float bv = h[0];
+  int bz = 0;
+  for (int z = 1; z < Z; ++z)
+    if (h[z] > bv) { bv = h[z]; bz = z; }       // first maximum
+  const long long ix = idx2d[size_t(i) * 2], iy = idx2d[size_t(i) * 2 + 1];
+  if (topk_index) {
+    topk_index[size_t(i) * 3 + 0] = ix;
+    topk_index[size_t(i) * 3 + 1] = iy;
+    topk_index[size_t(i) * 3 + 2] = bz;
+  }
+  const float conf = __fmul_rn(conf2d[i], bv);  // human_detection_net.py:101
+  float* c = centers + size_t(i) * 7;
+  // idx.float() * scale + bias: two roundings, no fma (human_detection_net.py:49)
+  c[0] = __fadd_rn(__fmul_rn(float(ix), sb[0]), sb[3]);
+  c[1] = __fadd_rn(__fmul_rn(float(iy), sb[1]), sb[4]);
+  c[2] = __fadd_rn(__fmul_rn(float(bz), sb[2]), sb[5]);
+  c[3] = (conf > min_score ? 1.0f : 0.0f) - 1.0f;
+  c[4] = conf;
+  c[5] = match_bbox[size_t(i) * 2];
+  c[6] = match_bbox[size_t(i) * 2 + 1];
+}
+
+}  // namespace fvp
+
+using namespace fvp;
+
+extern "C" int fvp_nms_topk(const float* hm2d, int B, int X, int Y, int N, float* vals, int64_t* idx, int64_t* flat,
+                            fvp_stream_t s) {
+  FVP_REQUIRE(hm2d && vals && idx && flat && B >= 0 && X > 0 && Y > 0 && N > 0);
+  FVP_LIMIT(size_t(X) * Y * 4 + 32 <= 64 * 1024 && N <= X * Y);
+  if (B == 0) return 0;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+  hipLaunchKernelGGL(k_nms_topk, dim3(B), dim3(256), size_t(X) * Y * 4 + 32, as_stream(s), hm2d, X, Y, N, vals,
+                     reinterpret_cast<long long*>(idx), reinterpret_cast<long long*>(flat));
+  return launch_status();
+}
+
+extern "C" int fvp_gather_proposals(const float* bbox_map, const float* cubes, const int64_t* flat, int B, int J,
+                                    int X, int Y, int Z, int N, float* bbox_flat, float* match_bbox, float* feat1d,
+                                    fvp_stream_t s) {
+  FVP_REQUIRE(bbox_map && cubes && flat && match_bbox && feat1d && B >= 0);
+  if (B == 0) return 0;
+  long total = long(B) * N * J * Z;
+  if (bbox_flat && long(B) * X * Y * 2 > total) total = long(B) * X * Y * 2;
+  if (long(B) * N * 2 > total) total = long(B) * N * 2;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+  hipLaunchKernelGGL(k_gather, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(s), bbox_map, cubes,
+                     reinterpret_cast<const long long*>(flat), B, J, X * Y, Z, N, bbox_flat, match_bbox, feat1d);
+  return launch_status();
+}
+
+extern "C" int fvp_proposals(const float* hm1d, const float* conf2d, const int64_t* idx2d, const float* match_bbox,
+                             const float* sb, float min_score, int B, int N, int Z, int64_t* topk_index,
+                             float* centers, fvp_stream_t s) {
+  FVP_REQUIRE(hm1d && conf2d && idx2d && match_bbox && sb && centers && B >= 0 && N > 0 && Z > 0);
+  if (B == 0) return 0;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+  hipLaunchKernelGGL(k_proposals, dim3(ceil_div(B * N, 64)), dim3(64), 0, as_stream(s), hm1d, conf2d,
+                     reinterpret_cast<const long long*>(idx2d), match_bbox, sb, min_score, B * N, Z,
+                     reinterpret_cast<long long*>(topk_index), centers);
+  return launch_status();
+}

@@ -1,0 +1,340 @@
+"""Host-side driver of the HIP hot path: owns geometry constants, packed weights and scratch
+buffers, and issues the C-ABI calls (``include/fvp.h``) on the caller's current HIP stream.
+
+No arithmetic happens here.  PyTorch is used for device memory, streams and the module /
+state_dict plumbing only.  One ``HotPath`` is shared by the HDN and JLN modules of a
+``FasterVoxelPoseNet`` so the channels-last heatmap staging is done once per batch.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from . import netspec
+
+BN_EPS = 1e-5
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HotPath:
+    def __init__(self, cfg, _lib=None):
+        # `_lib` is a test seam (tests/hipemu); the product always loads libfvp_hip.so
+        self._injected = _lib is not None
+        self.lib = _lib if _lib is not None else capi.load()
+        self.cfg = cfg
+        self.device = torch.device(cfg.DEVICE)
+        if not self._injected and self.device.type != "cuda":
+            raise capi.FvpError(f"cfg.DEVICE={cfg.DEVICE!r}: the HIP path needs a ROCm GPU device "
+                                "(spelled 'cuda:N' in PyTorch-ROCm); there is no CPU fallback")
+        ds, cs, ins = cfg.DATASET, cfg.CAPTURE_SPEC, cfg.INDIVIDUAL_SPEC
+        self.J = int(ds.NUM_JOINTS)
+        self.JP = (self.J + 3) // 4 * 4
+        self.W, self.H = int(ds.HEATMAP_SIZE[0]), int(ds.HEATMAP_SIZE[1])
+        self.N = int(cs.MAX_PEOPLE)
+        self.min_score = float(cs.MIN_SCORE)
+        self.X, self.Y, self.Z = (int(v) for v in cs.VOXELS_PER_AXIS)
+        self.C = int(ins.VOXELS_PER_AXIS[0])
+        assert len(set(int(v) for v in ins.VOXELS_PER_AXIS)) == 1, "cubic individual volume expected"
+        self.beta = float(cfg.NETWORK.BETA)
+        self.F = int(cfg.NETWORK.NUM_CHANNEL_JOINT_FEAT)
+        self.Hd = int(cfg.NETWORK.NUM_CHANNEL_JOINT_HIDDEN)
+        dev = self.device
+
+        # ---- constants, computed with the reference's own expressions (host, once) -----------
+        # voxel-centre axes: linspace(-S/2, S/2, n) + centre (project_whole.py:34-40)
+        def axes(size, center, nbins):
+            return [(torch.linspace(-size[a] / 2, size[a] / 2, int(nbins[a])) + center[a]).to(dev).contiguous()
+                    for a in range(3)]
+        self.whole_axes = axes(cs.SPACE_SIZE, cs.SPACE_CENTER, cs.VOXELS_PER_AXIS)
+        # ProposalLayer constants (human_detection_net.py:22-23)
+        scale = torch.tensor(cs.SPACE_SIZE) / (torch.tensor(cs.VOXELS_PER_AXIS) - 1)
+        bias = torch.tensor(cs.SPACE_CENTER) - torch.tensor(cs.SPACE_SIZE) / 2.0
+        self.prop_sb = torch.cat([scale, bias]).float().to(dev).contiguous()
+        # project_individual constants (project_individual.py:22-30)
+        whole_c = torch.tensor(cs.SPACE_CENTER)
+        whole_s = torch.tensor(cs.SPACE_SIZE)
+        ind_s = torch.tensor(ins.SPACE_SIZE)
+        cube = torch.tensor(ins.VOXELS_PER_AXIS, dtype=torch.int32)
+        fine = (whole_s / ind_s * (cube - 1)).int() + 1
+        ind_scale = (fine.float() - 1) / whole_s
+        ind_bias = -ind_s / 2.0 / whole_s * (fine - 1) - ind_scale * (whole_c - whole_s / 2.0)
+        self.fine = [int(v) for v in fine]
+        self.ind_consts = torch.cat([ind_scale, ind_bias, whole_s, ind_s]).float().to(dev).contiguous()
+        self.fine_cube = torch.tensor(self.fine + [int(v) for v in cube], dtype=torch.int32, device=dev)
+        self.fine_dev = torch.tensor(self.fine, dtype=torch.int32, device=dev)
+        self.fine_axes = axes(cs.SPACE_SIZE, cs.SPACE_CENTER, self.fine)
+        # center_grid [3, C*C, 2] (project_individual.py:37-40): xy at z0, xz at y0, yz at x0
+        ia = axes(ins.SPACE_SIZE, cs.SPACE_CENTER, ins.VOXELS_PER_AXIS)
+        gx, gy, gz = (a.cpu() for a in ia)
+        Cn = self.C
+        xy = torch.stack([gx.view(Cn, 1).expand(Cn, Cn), gy.view(1, Cn).expand(Cn, Cn)], dim=2).reshape(-1, 2)
+        xz = torch.stack([gx.view(Cn, 1).expand(Cn, Cn), gz.view(1, Cn).expand(Cn, Cn)], dim=2).reshape(-1, 2)
+        yz = torch.stack([gy.view(Cn, 1).expand(Cn, Cn), gz.view(1, Cn).expand(Cn, Cn)], dim=2).reshape(-1, 2)
+        self.center_grid = torch.stack([xy, xz, yz]).to(dev).contiguous()
+
+        # ---- conv stacks --------------------------------------------------------------------------
+        self.specs = {
+            "center_net": netspec.centernet_spec(self.J, self.X, self.Y),
+            "c2c_net": netspec.c2cnet_spec(self.J, self.Z),
+            "conv_net": netspec.p2pnet_spec(self.J, self.J, self.C),
+        }
+        self.params = {k: torch.zeros(max(s.nparams, 4), device=dev) for k, s in self.specs.items()}
+        self.wn_params = torch.zeros(self.F * 12 + self.Hd * self.F + 2 * self.Hd + 4, device=dev)
+        self._geom = None
+        self._geom_key = None
+        self._cams = None
+        self._seq_ids = {}
+        self._frame_sets = {}
+        self._heat_key = None
+        self._heat_cl = None
+        self._person_frame = {}
+        self._scratch = {}
+
+    # ---------------------------------------------------------------------------------------------
+    def stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _call(self, name, *args):
+        capi.check(self.lib, getattr(self.lib, name)(*args), name)
+
+    def _check_tensor(self, t, what):
+        if t.device != self.device and not (self.device.index is None and t.device.type == self.device.type):
+            raise capi.FvpError(f"{what} lives on {t.device}, the model was built for {self.device} (cfg.DEVICE)")
+        if t.dtype != torch.float32:
+            raise capi.FvpError(f"{what} must be float32, got {t.dtype}")
+
+    # ---- geometry / cameras ------------------------------------------------------------------------
+    def geom(self, resize_transform):
+        key = None
+        if isinstance(resize_transform, torch.Tensor):
+            key = (id(resize_transform), resize_transform.data_ptr(), resize_transform._version)
+            self._geom_ref = resize_transform      # pin the tensor so id / address cannot be recycled
+        if self._geom is None or key is None or key != self._geom_key:
+            rt = np.asarray(resize_transform.detach().cpu() if isinstance(resize_transform, torch.Tensor)
+                            else resize_transform, dtype=np.float32).reshape(6)
+            ds = self.cfg.DATASET
+            g = capi.FvpGeom()
+            g.clamp_max = float(max(ds.ORI_IMAGE_SIZE[0], ds.ORI_IMAGE_SIZE[1]))
+            for i in range(6):
+                g.rt[i] = float(rt[i])
+            g.hm_w, g.hm_h = float(self.W), float(self.H)
+            g.img_w, g.img_h = float(ds.IMAGE_SIZE[0]), float(ds.IMAGE_SIZE[1])
+            g.W, g.H = self.W, self.H
+            g.V = 0
+            g.J, g.JP = self.J, self.JP
+            self._geom, self._geom_key = g, key
+        return self._geom
+
+    @staticmethod
+    def _cam_row(cam):
+        """Camera dict (lists or numpy) -> 24 fp32 values, converted like
+        lib/utils/cameras.py:11-18 (float64 -> float32)."""
+        row = np.zeros(capi.FVP_CAM_FLOATS, np.float32)
+        row[0:9] = np.asarray(cam["R"], np.float64).reshape(9)
+        row[9:12] = np.asarray(cam["T"], np.float64).reshape(3)
+        row[12], row[13] = float(cam["fx"]), float(cam["fy"])
+        row[14], row[15] = float(cam["cx"]), float(cam["cy"])
+        row[16:19] = np.asarray(cam["k"], np.float64).reshape(3)
+        row[19:21] = np.asarray(cam["p"], np.float64).reshape(2)
+        return row
+
+    def frame_sets(self, meta, cameras, V):
+        """Per-frame camera-set ids (one set per sequence), uploading new sequences once."""
+        seqs = tuple(meta["seq"])
+        new = [s for s in dict.fromkeys(seqs) if s not in self._seq_ids]
+        for s in new:
+            assert s in cameras.keys(), "missing camera parameters for the current sequence"
+            assert len(cameras[s]) == V, "inconsistent number of cameras"
+            rows = np.stack([self._cam_row(cameras[s][c]) for c in range(V)])
+            t = torch.from_numpy(rows).to(self.device)
+            self._cams = t[None] if self._cams is None else torch.cat([self._cams, t[None]], dim=0)
+            self._seq_ids[s] = self._cams.shape[0] - 1
+            self._frame_sets.clear()
+        if seqs not in self._frame_sets:
+            self._frame_sets[seqs] = torch.tensor([self._seq_ids[s] for s in seqs], dtype=torch.int32,
+                                                  device=self.device)
+        return self._frame_sets[seqs]
+
+    def cams_of(self, seq):
+        return self._cams[self._seq_ids[seq]]
+
+    # ---- staging ---------------------------------------------------------------------------------------
+    def heat_cl(self, heatmaps, g, reuse=False):
+        """Channels-last staging of one batch.  ``reuse=True`` (only passed by
+        FasterVoxelPoseNet.forward, which hands the very same tensor to HDN and JLN) skips the
+        restaging when the tensor identity matches; any other caller restages."""
+        self._check_tensor(heatmaps, "heatmaps")
+        heatmaps = heatmaps.contiguous()
+        key = (heatmaps.data_ptr(), heatmaps._version, tuple(heatmaps.shape))
+        if not reuse or key != self._heat_key:
+            B, V = heatmaps.shape[:2]
+            out = self.scratch("heat_cl", (B, V, self.H, self.W, self.JP))
+            self._call("fvp_heatmaps_to_cl", _ptr(heatmaps), _ptr(out), B, C.byref(g), self.stream())
+            self._heat_cl, self._heat_key = out, key
+        return self._heat_cl
+
+    def invalidate_staging(self):
+        self._heat_key = None
+
+    def scratch(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._scratch.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._scratch[key] = t
+        if zero:
+            t.zero_()
+        return t
+
+    # ---- weights -----------------------------------------------------------------------------------------
+    def pack_stack(self, name, tree):
+        """state_dict tensors of one conv stack -> packed blob (fvp_pack_conv per conv)."""
+        spec, blob = self.specs[name], self.params[name]
+        s = self.stream()
+        for key, bn, transposed, oi in spec.param_keys:
+            w = tree.get(key + ".weight")
+            self._check_tensor(w, key)
+            b = tree.get(key + ".bias")
+            bnp = [None] * 4
+            if bn is not None:
+                bnp = [tree.get(bn + ".weight"), tree.get(bn + ".bias"), tree.get(bn + ".running_mean"),
+                       tree.get(bn + ".running_var")]
+            self._call("fvp_pack_conv", _ptr(w.contiguous()), _ptr(b), *[_ptr(t) for t in bnp], BN_EPS,
+                       1 if transposed else 0, C.byref(spec.op_array[oi]), _ptr(blob), s)
+
+    def pack_weightnet(self, tree):
+        g = tree.get
+        self._call("fvp_pack_weightnet", _ptr(g("heatmap_feature_net.0.weight").contiguous()),
+                   _ptr(g("heatmap_feature_net.0.bias")), _ptr(g("heatmap_feature_net.1.weight")),
+                   _ptr(g("heatmap_feature_net.1.bias")), _ptr(g("heatmap_feature_net.1.running_mean")),
+                   _ptr(g("heatmap_feature_net.1.running_var")), BN_EPS, _ptr(g("output.0.weight").contiguous()),
+                   _ptr(g("output.0.bias")), _ptr(g("output.2.weight").contiguous()), _ptr(g("output.2.bias")),
+                   self.F, self.Hd, _ptr(self.wn_params), self.stream())
+
+    # ---- conv stack ----------------------------------------------------------------------------------------
+    def run_stack(self, name, x, planes, plane_valid=None, valid_div=1):
+        spec = self.specs[name]
+        bufs = [x]
+        for i, (c, h, w) in enumerate(spec.bufs[1:], start=1):
+            bufs.append(self.scratch(f"{name}.buf{i}", (planes, c, h, w)))
+        arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+        self._call("fvp_conv_stack_run", spec.op_array, len(spec.ops), _ptr(self.params[name]), arr, len(bufs),
+                   planes, _ptr(plane_valid), valid_div, self.stream())
+        return {k: bufs[i] for k, i in spec.outputs.items()}
+
+    # ---- operator groups ------------------------------------------------------------------------------------
+    def project_whole(self, heatmaps, meta, cameras, resize_transform, want_cubes=True, want_zmax=False):
+        B, V = heatmaps.shape[:2]
+        g = self.geom(resize_transform)
+        g.V = V
+        fs = self.frame_sets(meta, cameras, V)
+        hcl = self.heat_cl(heatmaps, g)
+        cubes = torch.empty((B, self.J, self.X, self.Y, self.Z), device=self.device) if want_cubes else None
+        zmax = self.scratch("zmax", (B, self.J, self.X, self.Y)) if want_zmax else None
+        ax = self.whole_axes
+        self._call("fvp_project_whole", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
+                   self.X, self.Y, self.Z, B, C.byref(g), _ptr(cubes), _ptr(zmax), self.stream())
+        return cubes, zmax
+
+    def sample_grid(self, axes3, seq, resize_transform, V):
+        g = self.geom(resize_transform)
+        g.V = V
+        n = axes3[0].numel() * axes3[1].numel() * axes3[2].numel()
+        grid = torch.empty((V, 1, n, 2), device=self.device)
+        self._call("fvp_sample_grid", _ptr(axes3[0]), _ptr(axes3[1]), _ptr(axes3[2]), axes3[0].numel(),
+                   axes3[1].numel(), axes3[2].numel(), _ptr(self.cams_of(seq)), C.byref(g), _ptr(grid), self.stream())
+        return grid
+
+    def hdn(self, heatmaps, meta, cameras, resize_transform):
+        """HumanDetectionNet.forward (human_detection_net.py:76-104), inference branch."""
+        B = heatmaps.shape[0]
+        N, J, X, Y, Z = self.N, self.J, self.X, self.Y, self.Z
+        s = self.stream()
+        cubes, zmax = self.project_whole(heatmaps, meta, cameras, resize_transform, True, True)
+        heads = self.run_stack("center_net", zmax, B)
+        hm2d = heads["output_hm"].clone()
+        bbox_map = heads["output_size"]
+        dev = self.device
+        conf2d = self.scratch("conf2d", (B, N))
+        idx2d = self.scratch("idx2d", (B, N, 2), torch.int64)
+        flat = self.scratch("flat", (B, N), torch.int64)
+        self._call("fvp_nms_topk", _ptr(hm2d), B, X, Y, N, _ptr(conf2d), _ptr(idx2d), _ptr(flat), s)
+        bbox_flat = torch.empty((B, X * Y, 2), device=dev)
+        match_bbox = self.scratch("match_bbox", (B, N, 2))
+        feat1d = self.scratch("feat1d", (B * N, J, 1, Z))
+        self._call("fvp_gather_proposals", _ptr(bbox_map), _ptr(cubes), _ptr(flat), B, J, X, Y, Z, N, _ptr(bbox_flat),
+                   _ptr(match_bbox), _ptr(feat1d), s)
+        hm1d = self.run_stack("c2c_net", feat1d, B * N)["out"].view(B, N, Z).clone()
+        centers = torch.empty((B, N, 7), device=dev)
+        topk_index = self.scratch("topk_index", (B, N, 3), torch.int64)
+        self._call("fvp_proposals", _ptr(hm1d), _ptr(conf2d), _ptr(idx2d), _ptr(match_bbox), _ptr(self.prop_sb),
+                   self.min_score, B, N, Z, _ptr(topk_index), _ptr(centers), s)
+        self.last = dict(cubes=cubes, zmax=zmax, conf2d=conf2d, idx2d=idx2d, flat=flat, topk_index=topk_index,
+                         bbox_map=bbox_map)
+        return hm2d, hm1d, centers, bbox_flat
+
+    def person_frame(self, B, N):
+        key = (B, N)
+        if key not in self._person_frame:
+            self._person_frame[key] = (torch.arange(B * N, device=self.device) // N).to(torch.int32)
+        return self._person_frame[key]
+
+    def person_boxes(self, centers2d):
+        n = centers2d.shape[0]
+        boxes = self.scratch("boxes", (n, 9), torch.int32)
+        offset = self.scratch("offset", (n, 3))
+        self._call("fvp_person_boxes", _ptr(centers2d), n, _ptr(self.ind_consts), _ptr(self.fine_cube), _ptr(boxes),
+                   _ptr(offset), self.stream())
+        return boxes, offset
+
+    def jln(self, meta, heatmaps, proposal_centers, mask, cameras, resize_transform, fused=True,
+            reuse_staging=False):
+        """JointLocalizationNet.forward (joint_localization_net.py:64-99) for all B*N proposal
+        slots at once; invalid slots are skipped inside the kernels.  Writes the JLN
+        confidence into proposal_centers[..., 4] in place, as the reference does (:98)."""
+        B, N = proposal_centers.shape[:2]
+        V = heatmaps.shape[1]
+        J, Cn = self.J, self.C
+        nP = B * N
+        s = self.stream()
+        self._check_tensor(proposal_centers, "proposal_centers")
+        assert proposal_centers.is_contiguous(), "proposal_centers must be contiguous (it is updated in place)"
+        g = self.geom(resize_transform)
+        g.V = V
+        fs = self.frame_sets(meta, cameras, V)
+        hcl = self.heat_cl(heatmaps, g, reuse=reuse_staging)
+        valid = mask.reshape(-1).to(torch.uint8).contiguous()
+        pf = self.person_frame(B, N)
+        centers2d = proposal_centers.view(nP, 7)
+        boxes, offset = self.person_boxes(centers2d)
+        fa = self.fine_axes
+        planes = self.scratch("planes", (nP, 3, J, Cn, Cn), zero=True)
+        if fused:
+            self._call("fvp_project_individual_triplane", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),
+                       _ptr(boxes), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), _ptr(self.fine_dev), Cn, nP, C.byref(g),
+                       _ptr(planes), s)
+        else:
+            cubes = self.scratch("person_cubes", (nP, J, Cn, Cn, Cn))
+            self._call("fvp_project_individual", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),
+                       _ptr(boxes), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), _ptr(self.fine_dev), Cn, nP, C.byref(g),
+                       _ptr(cubes), s)
+            self._call("fvp_triplane_max", _ptr(cubes), _ptr(planes), nP, J, Cn, s)
+        feat = self.run_stack("conv_net", planes.view(nP * 3, J, Cn, Cn), nP * 3, valid, 3)["out"]
+        pose2d = self.scratch("pose2d", (nP, 3, J, 2))
+        pmax = self.scratch("pmax", (nP, 3, J))
+        wgt = self.scratch("wgt", (nP, 3, J))
+        self._call("fvp_softargmax_weightnet", _ptr(feat), _ptr(self.center_grid), _ptr(self.wn_params), self.beta, nP,
+                   J, Cn, self.F, self.Hd, _ptr(valid), _ptr(pose2d), _ptr(pmax), _ptr(wgt), s)
+        fused5 = torch.empty((B, N, J, 5), device=self.device)
+        plane_poses = torch.empty((3, B, N, J, 2), device=self.device)
+        self._call("fvp_fuse_poses", _ptr(pose2d), _ptr(pmax), _ptr(wgt), _ptr(offset), _ptr(valid), nP, J,
+                   _ptr(centers2d), _ptr(fused5), _ptr(plane_poses), s)
+        self.last_jln = dict(planes=planes, feat=feat, boxes=boxes, offset=offset, pose2d=pose2d, pmax=pmax, wgt=wgt,
+                             valid=valid)
+        return fused5, plane_poses

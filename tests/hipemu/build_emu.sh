@@ -1,0 +1,23 @@
+#!/usr/bin/env bash
+# Build the CPU emulation of the HIP kernels (TEST INFRASTRUCTURE ONLY): the unmodified
+# .hip sources are compiled for the host against tests/hipemu/hip/hip_runtime.h.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+csrc="${here}/../../faster-voxelpose_amd/csrc"
+CXX="${HIPEMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
+flags=(-x c++ -std=c++17 -O2 -fPIC -ffp-contract=off -I"${here}" -Wno-unused-function -Wno-unknown-attributes)
+objs=()
+for s in fvp_capi fvp_project fvp_conv fvp_proposal fvp_joint; do
+  o="${here}/${s}.emu.o"
+  if [[ ! -f "$o" || "$o" -ot "${csrc}/$s.hip" || "$o" -ot "${csrc}/fvp_common.h" || "$o" -ot "${csrc}/fvp_geom.h" \
+        || "$o" -ot "${here}/hip/hip_runtime.h" || "$o" -ot "${here}/../../include/fvp.h" ]]; then
+    "$CXX" "${flags[@]}" -c "${csrc}/$s.hip" -o "$o" &
+  fi
+  objs+=("$o")
+done
+o="${here}/hipemu.emu.o"
+"$CXX" "${flags[@]}" -c "${here}/hipemu.cpp" -o "$o" &
+objs+=("$o")
+wait
+"$CXX" -shared -fPIC "${objs[@]}" -o "${here}/libfvp_emu.so" -lpthread
+echo "built ${here}/libfvp_emu.so"

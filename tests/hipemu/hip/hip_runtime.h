@@ -1,0 +1,148 @@
+/*
+ * hipemu - a minimal HIP execution-model emulator for the CPU.  TEST INFRASTRUCTURE ONLY.
+ *
+ * The build container has no GPU.  To check the *logic* of the gfx950 kernels in
+ * faster-voxelpose_amd/csrc (indexing, LDS tiling, barriers, wave shuffles, MFMA fragment
+ * layouts) before spending GPU minutes, the unmodified .hip sources are compiled a second
+ * time with the host clang against this header (it shadows <hip/hip_runtime.h>) into
+ * tests/hipemu/libfvp_emu.so.  Only `-m "not gpu"` tests load that library, by explicit
+ * path, with numpy buffers standing in for device memory.  The product package never
+ * loads it and has no CPU execution path.
+ *
+ * Model: each workgroup runs as blockDim cooperative fibers on one OS thread (workgroups
+ * are spread over OS threads); __syncthreads and the wave-collective operations
+ * (__shfl*, MFMA) are rendezvous points.  `__shared__` becomes `static thread_local`.
+ * v_mfma_f32_32x32x2_f32 follows the lane layout documented for gfx950: A[i=l&31][k=l>>5],
+ * B[k=l>>5][j=l&31], D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), computed as the
+ * k-ordered fmaf chain the hardware produces.
+ */
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_smem());
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+
+namespace hipemu {
+struct Ctx {
+  dim3 tid, bid, bdim, gdim;
+  int lane, wave;
+};
+extern thread_local Ctx* cur;
+char* dyn_smem();
+void block_barrier();
+// wave rendezvous: every lane deposits `n` 32-bit words, then may read any lane's words
+void wave_exchange(const uint32_t* mine, int n, uint32_t (*all)[4]);
+void wave_exchange_done();
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur->tid)
+#define blockIdx (hipemu::cur->bid)
+#define blockDim (hipemu::cur->bdim)
+#define gridDim (hipemu::cur->gdim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+
+template <typename... KArgs, typename... Args>
+static inline void hipLaunchKernelGGL(void (*k)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t,
+                                      Args... args) {
+  hipemu::launch(grid, block, shmem, [=]() { k(args...); });
+}
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+
+// ---- cross-lane -------------------------------------------------------------------------
+template <typename T>
+static inline T hipemu_shfl_from(T v, int src) {
+  static_assert(sizeof(T) == 4, "32-bit shuffles only");
+  uint32_t mine[1];
+  memcpy(mine, &v, 4);
+  uint32_t all[64][4];
+  hipemu::wave_exchange(mine, 1, all);
+  T r;
+  memcpy(&r, &all[src & 63][0], 4);
+  hipemu::wave_exchange_done();
+  return r;
+}
+template <typename T> static inline T __shfl_xor(T v, int m, int = 64) { return hipemu_shfl_from(v, hipemu::cur->lane ^ m); }
+template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
+  int s = hipemu::cur->lane + d;
+  return hipemu_shfl_from(v, s > 63 ? hipemu::cur->lane : s);
+}
+template <typename T> static inline T __shfl(T v, int src, int = 64) { return hipemu_shfl_from(v, src); }
+
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+  uint32_t mine[2];
+  memcpy(&mine[0], &a, 4);
+  memcpy(&mine[1], &b, 4);
+  uint32_t all[64][4];
+  hipemu::wave_exchange(mine, 2, all);
+  const int l = hipemu::cur->lane, col = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av, bv;
+      memcpy(&av, &all[row + 32 * k][0], 4);
+      memcpy(&bv, &all[col + 32 * k][1], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  hipemu::wave_exchange_done();
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
+
+// ---- scalar intrinsics -------------------------------------------------------------------
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline long long __double_as_longlong(double d) { long long i; memcpy(&i, &d, 8); return i; }
+static inline double __longlong_as_double(long long i) { double d; memcpy(&d, &i, 8); return d; }
+static inline int atomicMax(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
