@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Throughput of the heatmaps -> 3-D joints hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A step = one pass of the whole hot path (staging, HDN, JLN, fusion) over one batch of B
+synthetic frames per GPU: Panoptic shape set (5 views, 15 joints, 240x128 heatmaps, 80x80x20
+voxels, jln64, MAX_PEOPLE 10), Gaussian-blob heatmaps resident in HBM, seeded random weights,
+MIN_SCORE = -1 so that all 10 proposals per frame are valid (P = 10, the FLOP count
+BASELINE.md quotes).  Frames shard across ranks (one process per GPU, weak scaling); the only
+collective is an all_gather of the [B,10,15,5] result.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak
+
+
+def shard_frames(total_frames, world, rank):
+    """Contiguous B/G frames per rank."""
+    per = total_frames // world
+    return rank * per, (rank + 1) * per
+
+
+def gather_results(local, world):
+    """all_gather of the per-rank [B/G,N,J,5] results (RCCL on GPUs, gloo in the CPU tests)."""
+    if world == 1:
+        return local
+    out = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(out, local)
+    return torch.cat(out, dim=0)
+
+
+def algorithmic_bytes_projection(V, J, H, W, C, people_per_frame):
+    """fused project_individual -> tri-plane: heatmaps read once per frame + 3 planes written per
+    person: 4*V*J*H*W + P*3*4*J*C*C bytes per frame."""
+    return 4.0 * V * J * H * W + people_per_frame * 3 * 4.0 * J * C * C
+
+
+def cpu_baseline(cfg_name, frames, seed):
+    """The CPU oracle (a port of the reference's PyTorch path, pinned against the reference's
+    golden vectors) on the host cores of this box, same workload, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fvp_oracle as O
+    import faster_voxelpose_amd.synthetic as S
+    cfg = S.make_cfg(cfg_name, device="cpu", min_score=-1.0)
+    cams, seq = S.load_cameras(cfg_name)
+    rt = S.resize_transform(cfg)
+    heat = S.heatmaps_blobs(cfg, cams, seq, 1, people=4, seed=seed)
+    orc = O.Oracle(cfg, S.fill_state_dict(O.reference_state_dict_shapes(cfg), seed=7))
+    meta = {"seq": [seq]}
+    orc.forward(heat, meta, cams, rt)                      # warm-up (builds the sampling grid)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        orc.forward(heat, meta, cams, rt)
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{frames} single-frame passes (P=10) of the same Panoptic workload, torch-CPU oracle, "
+                      f"{torch.get_num_threads()} threads, {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--config", default="panoptic")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import faster_voxelpose_amd.synthetic as S
+    from faster_voxelpose_amd import _capi as capi
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+
+    cfg = S.make_cfg(args.config, device=dev, min_score=-1.0)
+    cams, seq = S.load_cameras(args.config)
+    rt = S.resize_transform(cfg).to(dev)
+    B = args.batch
+    # weak scaling: every rank owns B frames; a distinct seed per rank keeps the data distinct
+    lo, hi = shard_frames(B * world, world, rank)
+    heat = S.heatmaps_blobs(cfg, cams, seq, B, people=4, seed=100 + rank).to(dev)
+    meta = {"seq": [seq] * B}
+    model = FV.get(cfg).to(dev)
+    model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
+    lib = capi.load()
+
+    def step():
+        fused, planes, centers, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        return gather_results(fused, world)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if not args.no_prof:
+            lib.fvp_prof_reset()
+            lib.fvp_prof_enable(1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    lib.fvp_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape[0] == B * world
+    valid_people = float((out[..., 0, 3] >= 0).sum().item()) / out.shape[0]
+
+    if rank == 0:
+        names = {capi.K_PROJECT_WHOLE: "project_whole", capi.K_PROJECT_TRIPLANE: "project_triplane",
+                 capi.K_CONV: "conv_mfma", capi.K_SOFTARGMAX: "softargmax_weightnet", capi.K_OTHER: "other"}
+        kern = {}
+        if not args.no_prof:
+            for cls, nm in names.items():
+                ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+                lib.fvp_prof_read(cls, C.byref(ms), C.byref(n), C.byref(fl))
+                kern[nm] = {"ms_total": ms.value, "launches": n.value, "flops": fl.value}
+        J, V = cfg.DATASET.NUM_JOINTS, cfg.DATASET.CAMERA_NUM
+        W, H = cfg.DATASET.HEATMAP_SIZE
+        Cn = cfg.INDIVIDUAL_SPEC.VOXELS_PER_AXIS[0]
+        roof = None
+        if kern:
+            conv, proj = kern["conv_mfma"], kern["project_triplane"]
+            conv_tf = conv["flops"] / (conv["ms_total"] * 1e-3) / 1e12 if conv["ms_total"] > 0 else 0.0
+            pbytes = algorithmic_bytes_projection(V, J, H, W, Cn, valid_people) * B * args.steps
+            proj_gbs = pbytes / (proj["ms_total"] * 1e-3) / 1e9 if proj["ms_total"] > 0 else 0.0
+            # dominant kernel by accumulated time decides which roofline is the headline
+            if conv["ms_total"] >= proj["ms_total"]:
+                roof = {"kernel": "k_conv (fp32 MFMA implicit GEMM, all conv launches)", "bound": "mfma",
+                        "achieved": conv_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": conv_tf / MFMA_F32_PEAK_TF, "traffic": None,
+                        "avg_launch_us": 1e3 * conv["ms_total"] / max(conv["launches"], 1)}
+            else:
+                roof = {"kernel": "k_project_triplane", "bound": "hbm", "achieved": proj_gbs, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": proj_gbs / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": 1e3 * proj["ms_total"] / max(proj["launches"], 1)}
+            kern["conv_mfma"]["tflops"] = conv_tf
+            kern["project_triplane"]["algorithmic_GBps"] = proj_gbs
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.config, args.cpu_frames, 100)
+        frames = B * world * args.steps
+        line = {
+            "metric": "frames/sec at 5-view 80x80x20 voxel (heatmaps -> 3D joints)",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}-shape 5-view synthetic heatmaps, 80x80x20, jln64, "
+                                   f"{B} frames/GPU/step, {valid_people:.1f} valid people/frame (MIN_SCORE=-1), "
+                                   "seeded random weights", "frames_per_gpu_per_step": B,
+                       "parallelism": f"frame-sharded dp{world}, all_gather of results"},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

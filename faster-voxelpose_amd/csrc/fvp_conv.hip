@@ -312,7 +312,7 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   if (CB != 1 && CB != 2 && CB != 4) return FVP_ELIMIT;
   // pixels per plane decide PB (PB*128 pixels per workgroup)
   const int hw = op.h * op.w;
-  int PB = CB == 1 ? 4 : (CB == 2 ? 4 : 2);
+  int PB = CB == 1 ? 4 : (CB == 2 ? 2 : 1);   // CB*PB = 4 accumulator tiles: ~141 registers, 3 waves/SIMD
   while (PB > 1 && PB * 128 > hw * (planes > 0 ? planes : 1)) PB >>= 1;
   if (hw * planes < 128) PB = 1;
   const int TP = PB * 128;

@@ -462,3 +462,73 @@ class Oracle:
             J = heatmaps.shape[2]
             fused = torch.cat([fused, centers[:, :, 3:5].reshape(B, N, 1, 2).repeat(1, 1, J, 1)], dim=3)
         return fused, planes, centers
+
+
+# --------------------------------------------------------------------------------------
+# checkpoint layout (key names / shapes), restated from the reference's module definitions
+# --------------------------------------------------------------------------------------
+def reference_state_dict_shapes(cfg):
+    """Ordered {key: zeros tensor} with the key names and shapes of
+    ``FasterVoxelPoseNet(cfg).state_dict()`` (485 entries for the shipped configs):
+    pose_net.center_net.* (cnns_2d.py:147-171), pose_net.c2c_net.* (cnns_1d.py:112-126),
+    joint_net.conv_net.* (cnns_2d.py:115-129), joint_net.weight_net.* (weight_net.py:48-67).
+    Module registration order is the reference's ``__init__`` order."""
+    J = cfg.DATASET.NUM_JOINTS
+    F, Hd = cfg.NETWORK.NUM_CHANNEL_JOINT_FEAT, cfg.NETWORK.NUM_CHANNEL_JOINT_HIDDEN
+    out = {}
+
+    def conv(key, cin, cout, k, dim, transposed=False):
+        out[key + ".weight"] = torch.zeros(((cin, cout) if transposed else (cout, cin)) + (k,) * dim)
+        out[key + ".bias"] = torch.zeros(cout)
+
+    def bn(key, c):
+        out[key + ".weight"] = torch.zeros(c)
+        out[key + ".bias"] = torch.zeros(c)
+        out[key + ".running_mean"] = torch.zeros(c)
+        out[key + ".running_var"] = torch.ones(c)
+        out[key + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    def res(pre, cin, cout, dim):
+        conv(pre + ".res_branch.0", cin, cout, 3, dim)
+        bn(pre + ".res_branch.1", cout)
+        conv(pre + ".res_branch.3", cout, cout, 3, dim)
+        bn(pre + ".res_branch.4", cout)
+        if cin != cout:
+            conv(pre + ".skip_con.0", cin, cout, 1, dim)
+            bn(pre + ".skip_con.1", cout)
+
+    def up(pre, cin, cout, dim):
+        conv(pre + ".block.0", cin, cout, 2, dim, transposed=True)
+        bn(pre + ".block.1", cout)
+
+    def trunk(pre, dim):
+        conv(pre + ".front_layers.0.block.0", J, 16, 7, dim)
+        bn(pre + ".front_layers.0.block.1", 16)
+        res(pre + ".front_layers.1", 16, 32, dim)
+        ed = pre + ".encoder_decoder"
+        res(ed + ".encoder_res1", 32, 64, dim)
+        res(ed + ".encoder_res2", 64, 128, dim)
+        res(ed + ".mid_res", 128, 128, dim)
+        res(ed + ".decoder_res2", 128, 128, dim)
+        up(ed + ".decoder_upsample2", 128, 64, dim)
+        res(ed + ".decoder_res1", 64, 64, dim)
+        up(ed + ".decoder_upsample1", 64, 32, dim)
+        res(ed + ".skip_res1", 32, 32, dim)
+        res(ed + ".skip_res2", 64, 64, dim)
+
+    trunk("pose_net.center_net", 2)
+    for name, c in (("output_hm", 1), ("output_size", 2)):
+        conv(f"pose_net.center_net.{name}.0", 32, 32, 3, 2)
+        conv(f"pose_net.center_net.{name}.2", 32, c, 1, 2)
+    trunk("pose_net.c2c_net", 1)
+    conv("pose_net.c2c_net.output_hm", 32, 1, 1, 1)
+    trunk("joint_net.conv_net", 2)
+    conv("joint_net.conv_net.output_layer", 32, J, 1, 2)
+    wn = "joint_net.weight_net"
+    conv(wn + ".heatmap_feature_net.0", 1, F, 3, 2)
+    bn(wn + ".heatmap_feature_net.1", F)
+    out[wn + ".output.0.weight"] = torch.zeros(Hd, F)
+    out[wn + ".output.0.bias"] = torch.zeros(Hd)
+    out[wn + ".output.2.weight"] = torch.zeros(1, Hd)
+    out[wn + ".output.2.bias"] = torch.zeros(1)
+    return out

@@ -1,0 +1,166 @@
+"""Parity of the HIP path on a real MI355X: golden vectors from the reference, the CPU oracle,
+and size-independent properties at BASELINE.json's full sizes.  Everything goes through the
+C ABI (libfvp_hip.so) via the reference-shaped modules."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fvp_oracle as O
+from cases import CASES, make_inputs
+from common import check_outputs, load_golden
+import faster_voxelpose_amd.synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
+
+
+def build(case_or_cfg, wseed=7):
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = case_or_cfg
+    model = FV.get(cfg).to(DEV)
+    sd = S.fill_state_dict(model.state_dict(), seed=wseed)
+    model.load_state_dict(sd)
+    return model, sd
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_golden_case(case):
+    cfg, cams, seq, rt, heat, meta, wseed = make_inputs(case, device=DEV)
+    model, _ = build(cfg, wseed)
+    with torch.no_grad():
+        fused, planes, centers, hm, loss = model(meta=meta, input_heatmaps=heat.to(DEV), cameras=cams,
+                                                 resize_transform=rt.to(DEV))
+    torch.cuda.synchronize()
+    assert loss is None and hm.shape == heat.shape
+    report = {}
+    try:
+        check_outputs(case, load_golden(case), fused, planes, centers, model.engine, report)
+    finally:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps(report) + "\n")
+        print(report)
+
+
+def test_fused_projection_equals_materialised_full_size():
+    """Panoptic jln64: fvp_project_individual_triplane == fvp_project_individual + fvp_triplane_max,
+    bit for bit, and the drop-in ProjectLayer cubes have the reference's per-person checksums."""
+    case = "panoptic_g_b1_all"
+    cfg, cams, seq, rt, heat, meta, wseed = make_inputs(case, device=DEV)
+    g = load_golden(case)
+    model, _ = build(cfg, wseed)
+    heat, rt = heat.to(DEV), rt.to(DEV)
+    with torch.no_grad():
+        f1, p1, c1, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        planes_fused = model.engine.last_jln["planes"].clone()
+        model.joint_net.fused_projection = False
+        f2, p2, c2, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        assert torch.equal(model.engine.last_jln["planes"], planes_fused)
+        assert torch.equal(f1, f2) and torch.equal(p1, p2) and torch.equal(c1, c2)
+        pc = torch.from_numpy(g["proposal_centers_hdn"][0]).to(DEV)
+        cubes, offset = model.joint_net.project_layer(heat, 0, meta, pc, cams, rt)
+    np.testing.assert_allclose(cubes.double().sum(dim=(1, 2, 3, 4)).cpu().numpy(), g["jl0_cubes_sum"], rtol=1e-12)
+    np.testing.assert_allclose((cubes.double() ** 2).sum(dim=(1, 2, 3, 4)).cpu().numpy(), g["jl0_cubes_sq"], rtol=1e-12)
+    assert np.array_equal(offset.cpu().numpy(), g["jl0_offset"])
+
+
+def test_batch_invariance_and_determinism_full_size():
+    """Frames are independent units: a batch of 4 Panoptic frames equals the 4 single-frame runs
+    bit for bit (the property the multi-GPU sharding relies on), and repeating a run is bit-stable."""
+    cfg = S.make_cfg("panoptic", device=DEV, min_score=17.0)
+    cams, seq = S.load_cameras("panoptic")
+    rt = S.resize_transform(cfg).to(DEV)
+    heat = S.heatmaps_blobs(cfg, cams, seq, 4, people=3, seed=21).to(DEV)
+    model, _ = build(cfg)
+    with torch.no_grad():
+        fb, pb, cb, _, _ = model(meta={"seq": [seq] * 4}, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        fb2, _, _, _, _ = model(meta={"seq": [seq] * 4}, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        assert torch.equal(fb, fb2)
+        assert 0 < int((cb[..., 3] >= 0).sum()) < 40, "fixture should mix valid and invalid proposals"
+        for i in range(4):
+            f1, p1, c1, _, _ = model(meta={"seq": [seq]}, input_heatmaps=heat[i:i + 1].contiguous(), cameras=cams,
+                                     resize_transform=rt)
+            assert torch.equal(f1[0], fb[i]) and torch.equal(c1[0], cb[i]) and torch.equal(p1[:, 0], pb[:, i])
+
+
+def test_two_sequences_in_one_batch():
+    """meta['seq'] may differ per frame: each frame uses its own camera set."""
+    cfg = S.make_cfg("panoptic", device=DEV, min_score=-1.0)
+    cams, seq = S.load_cameras("panoptic")
+    import copy
+    cams2 = copy.deepcopy(cams[seq])
+    for c in cams2:
+        c["T"] = [[c["T"][0][0] + 150.0], [c["T"][1][0] - 80.0], [c["T"][2][0]]]
+    cameras = {seq: cams[seq], "shifted": cams2}
+    rt = S.resize_transform(cfg).to(DEV)
+    heat = S.heatmaps_blobs(cfg, cams, seq, 2, people=3, seed=5).to(DEV)
+    model, _ = build(cfg)
+    with torch.no_grad():
+        fb, _, cb, _, _ = model(meta={"seq": [seq, "shifted"]}, input_heatmaps=heat, cameras=cameras, resize_transform=rt)
+        f0, _, c0, _, _ = model(meta={"seq": [seq]}, input_heatmaps=heat[0:1].contiguous(), cameras=cameras, resize_transform=rt)
+        f1, _, c1, _, _ = model(meta={"seq": ["shifted"]}, input_heatmaps=heat[1:2].contiguous(), cameras=cameras, resize_transform=rt)
+    assert torch.equal(fb[0], f0[0]) and torch.equal(fb[1], f1[0])
+    assert not torch.equal(cb[0], cb[1])
+
+
+def test_empty_and_all_invalid():
+    """No valid proposal at all (threshold above every confidence): zero joints, flags -1,
+    HDN confidences kept; and an empty batch is accepted by every C-ABI call it reaches."""
+    cfg = S.make_cfg("campus", device=DEV, min_score=1e9)
+    cams, seq = S.load_cameras("campus")
+    rt = S.resize_transform(cfg).to(DEV)
+    heat = S.heatmaps_uniform(cfg, 2, seed=4).to(DEV)
+    model, _ = build(cfg)
+    with torch.no_grad():
+        fused, planes, centers, _, _ = model(meta={"seq": [seq] * 2}, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+    assert torch.all(fused[..., :3] == 0) and torch.all(fused[..., 3] == -1) and torch.all(planes == 0)
+    assert torch.equal(fused[..., 0, 4], centers[..., 4])
+
+
+def test_nms_topk_exact_vs_oracle():
+    from faster_voxelpose_amd.core.proposal import nms2D
+    rng = np.random.default_rng(3)
+    for (B, X, Y, N) in ((5, 80, 80, 10), (2, 128, 128, 10), (3, 16, 16, 7)):
+        m = torch.from_numpy(rng.normal(size=(B, 1, X, Y)).astype(np.float32))
+        m[0, 0, 0, 0] = m[0, 0, X - 1, Y - 1] = 9.0      # tie -> lowest index first
+        m[1, 0, 3, 3] = m[1, 0, 3, 4] = 8.0              # plateau
+        vals, idx, flat = nms2D(m.to(DEV), N)
+        ov, oi, of = O.nms2d(m, N)
+        assert torch.equal(flat.cpu(), of) and torch.equal(idx.cpu(), oi) and torch.equal(vals.cpu(), ov)
+
+
+def test_conv_stacks_vs_torch_fp32():
+    """MFMA implicit-GEMM stacks vs the plain PyTorch fp32 restatement (oracle, CPU) at full
+    Panoptic sizes, ragged plane counts included."""
+    cfg = S.make_cfg("panoptic", device=DEV)
+    model, sd = build(cfg)
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.random((7, 15, 64, 64), dtype=np.float32))
+    want = O.p2p_net(sd, "joint_net.conv_net", x)
+    got = model.joint_net.conv_net(x.to(DEV)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+    cubes = torch.from_numpy(rng.random((3, 15, 80, 80, 20), dtype=np.float32))
+    hm_w, sz_w = O.center_net(sd, "pose_net.center_net", cubes)
+    hm, sz = model.pose_net.center_net(cubes.to(DEV))
+    np.testing.assert_allclose(hm.cpu().numpy(), hm_w.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(sz.cpu().numpy(), sz_w.numpy(), rtol=2e-5, atol=2e-5)
+    z = torch.from_numpy(rng.random((23, 15, 20), dtype=np.float32))
+    np.testing.assert_allclose(model.pose_net.c2c_net(z.to(DEV)).cpu().numpy(),
+                               O.c2c_net(sd, "pose_net.c2c_net", z).numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_missing_sequence_and_wrong_device_fail_loudly():
+    from faster_voxelpose_amd import _capi as capi
+    cfg = S.make_cfg("campus", device=DEV)
+    cams, seq = S.load_cameras("campus")
+    rt = S.resize_transform(cfg).to(DEV)
+    model, _ = build(cfg)
+    heat = S.heatmaps_uniform(cfg, 1, seed=4)
+    with pytest.raises(AssertionError):
+        model(meta={"seq": ["nope"]}, input_heatmaps=heat.to(DEV), cameras=cams, resize_transform=rt)
+    with pytest.raises(capi.FvpError):
+        model(meta={"seq": [seq]}, input_heatmaps=heat, cameras=cams, resize_transform=rt)   # CPU tensor

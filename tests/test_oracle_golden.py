@@ -1,0 +1,85 @@
+"""Pin the CPU oracle against the golden vectors captured from the reference
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import fvp_oracle as O
+from cases import CASES, make_inputs
+from common import load_golden
+import faster_voxelpose_amd.synthetic as S
+
+
+def state_dict_for(cfg, wseed):
+    return S.fill_state_dict(O.reference_state_dict_shapes(cfg), seed=wseed)
+
+
+def test_checkpoint_layout_restatement_matches_product_modules():
+    """The oracle's independent restatement of the reference's state_dict layout and the
+    product's module tree agree key for key (order and shapes)."""
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    for name in ("panoptic", "shelf", "tiny"):
+        cfg = S.make_cfg(name, device="cpu")
+        want = O.reference_state_dict_shapes(cfg)
+        got = FV.FasterVoxelPoseNet(cfg, _lib=object()).state_dict()
+        assert list(want) == list(got)
+        assert all(want[k].shape == got[k].shape for k in want)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_oracle_matches_reference_golden(case):
+    cfg, cams, seq, rt, heat, meta, wseed = make_inputs(case)
+    g = load_golden(case)
+    orc = O.Oracle(cfg, state_dict_for(cfg, wseed))
+    fused, planes, centers = orc.forward(heat, meta, cams, rt)
+    # sampling grid: bit-equal (same torch ops in the same order)
+    stride = int(g["grid_stride"])
+    assert np.array_equal(orc._grids[seq][:, ::stride].numpy(), g["grid_digest"])
+    # cubes: own bilinear restatement vs F.grid_sample: <= 2 ulp of 1.0
+    sx, sy = g["cubes_sub_stride"]
+    np.testing.assert_allclose(orc.trace["cubes"][:, :, ::sx, ::sy, :].numpy(), g["cubes_sub"], rtol=0, atol=2.5e-7)
+    np.testing.assert_allclose(orc.trace["hm2d"][:, 0].numpy(), g["hm2d"], rtol=0, atol=2e-5)
+    # integer / index work: exact
+    ti = orc.trace["topk_index"].numpy()
+    X = cfg.CAPTURE_SPEC.VOXELS_PER_AXIS[0]
+    assert np.array_equal(ti[..., 0] * X + ti[..., 1], g["topk_flat"])
+    c = centers.numpy()
+    assert np.array_equal(c[..., :3], g["proposal_centers"][..., :3])
+    assert np.array_equal(c[..., 3], g["proposal_centers"][..., 3])
+    v = g["valid"]
+    for f in range(v.shape[0]):
+        if f"jl{f}_tl" not in g:
+            continue
+        tl, start, end = orc.trace["jln"][f]["boxes"]
+        assert np.array_equal(tl.numpy(), g[f"jl{f}_tl"])
+        assert np.array_equal(start.numpy(), g[f"jl{f}_start"])
+        assert np.array_equal(end.numpy(), g[f"jl{f}_end"])
+        assert np.array_equal(orc.trace["jln"][f]["offset"].numpy(), g[f"jl{f}_offset"])
+    # joints: the oracle uses the reference's own conv kernels, so it sits well inside the floor
+    d = np.linalg.norm((fused[..., :3].numpy() - g["fused_poses"][..., :3])[v], axis=-1)
+    floor = float(g["margins"][5])
+    assert d.max() <= max(1e-3, 3 * floor), (d.max(), floor)
+    assert np.all(fused[..., :3].numpy()[~v] == 0)
+
+
+def test_resize_transform_constants():
+    """the 2x3 resize transforms of the three shipped configs."""
+    expect = {"panoptic": [[0.474074, 0, 24.888889], [0, 0.474074, 0]],
+              "shelf": [[0.775194, 0, 0], [0, 0.775194, 3.224806]],
+              "campus": [[2.222222, 0, 0], [0, 2.222222, 0]]}
+    for name, e in expect.items():
+        rt = S.resize_transform(S.make_cfg(name)).numpy()
+        np.testing.assert_allclose(rt, np.array(e), atol=1e-5)
+
+
+def test_nms_tie_rule_and_padding():
+    """max-pool NMS keeps plateaus and uses -inf padding; ties resolve to the lowest index."""
+    m = torch.zeros(1, 1, 6, 6)
+    m[0, 0, 0, 0] = 1.0
+    m[0, 0, 3, 3] = 1.0
+    m[0, 0, 3, 4] = 1.0          # plateau: both kept
+    m[0, 0, 5, 5] = -2.0         # below the zero background: suppressed to (-)0
+    vals, idx, flat = O.nms2d(m, 4)
+    assert flat[0].tolist()[:3] == [0, 21, 22]
+    assert vals[0].tolist()[:3] == [1.0, 1.0, 1.0]
+    assert idx[0, 1].tolist() == [3, 3]

@@ -1,0 +1,28 @@
+#!/usr/bin/env bash
+# One GPU-box visit: smoke, GPU parity tests, bench, rocprofv3 kernel trace.  Logs -> gpurun_out/.
+# Usage (from the build container):  gpurun --timeout 1500 -- 'bash tools/gpu_check.sh [tag]'
+tag="${1:-r01}"
+root="${GRAFT_REPO_ROOT:-$(pwd)}"
+out="$root/gpurun_out"
+mkdir -p "$out"
+cd "$root"
+export TMPDIR=/tmp
+rocm-smi --showproductname 2>/dev/null | head -8 > "$out/gpu.txt"
+lscpu | grep -E "Model name|^CPU\(s\)|Socket|Core" >> "$out/gpu.txt"
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$out/smoke.log"
+echo "== pytest -m gpu"; rm -f "$out/parity_report.jsonl"; timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -25 "$out/pytest_gpu.log"
+echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 3 > "$out/bench_${tag}.json" 2> "$out/bench_${tag}.err"; echo "bench rc=$?"; cat "$out/bench_${tag}.json"; tail -3 "$out/bench_${tag}.err"
+for b in 1 2 16 32; do
+  timeout 600 python bench.py --steps 10 --warmup 2 --batch $b --no-cpu-baseline > "$out/bench_${tag}_b$b.json" 2>> "$out/bench_${tag}.err"
+  python - "$out/bench_${tag}_b$b.json" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1])); print("batch", d["config"]["frames_per_gpu_per_step"], "frames/s %.1f" % d["value"], "ms/step %.2f" % d["ms_per_step"], {k: round(v["ms_total"], 2) for k, v in d["kernels"].items()})
+except Exception as e:
+    print("bench sweep failed", e)
+PY
+done
+echo "== rocprofv3 kernel trace"
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-prof > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
+find "$out/prof_${tag}" -name "*kernel_stats*.csv" | head -1 | xargs -r head -30
