@@ -10,7 +10,12 @@ for s in "${srcs[@]}"; do
   o="${here}/${s%.hip}.o"
   if [[ ! -f "$o" || "$o" -ot "${here}/$s" || "$o" -ot "${here}/fvp_common.h" || "$o" -ot "${here}/fvp_geom.h" \
         || "$o" -ot "${here}/../../include/fvp.h" ]]; then
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "${here}/$s" -o "$o" &
+    # geometry / proposal / fusion code mirrors the reference's separately-rounded fp32 ops:
+    # no fma contraction there (HIP's __fmul_rn/__fadd_rn are plain operators); the MFMA conv
+    # file keeps the default.
+    extra=(-ffp-contract=off)
+    [[ "$s" == "fvp_conv.hip" ]] && extra=()
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" -c "${here}/$s" -o "$o" &
   fi
   objs+=("$o")
 done

@@ -25,6 +25,8 @@
 namespace fvp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kStageU = 4;   // independent 16-byte loads in flight per thread while staging
+constexpr int kStageS = 8;   // same for the 4-byte generic path
 
 struct ConvArgs {
   const float* src;
@@ -42,17 +44,24 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int CC;             // input channels per LDS chunk (even)
   int flags;
+  int vec;            // 1: full-width tile with W % 4 == 0 -> 16-byte staging, margin layout
   int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
   int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
 };
 
+// Branch-free staging helpers: every thread computes kU addresses, issues kU independent
+// loads (out-of-range items read a valid dummy address and are masked afterwards -- a branch
+// around a load makes hipcc wait for each one separately), then writes LDS.
 template <int KH, int KW, int CB, int PB>
 __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
   constexpr int KK = KH * KW;
+  constexpr int CBW = 32 * CB;               // couts of this workgroup
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int THp = a.TH + KH - 1, TWp = a.TW + KW - 1;
+  // LDS row stride: vector layout = 4 floats margin | TW | 4 floats margin (16-byte aligned rows)
+  const int THp = a.TH + KH - 1, TWp = a.vec ? a.TW + 8 : a.TW + KW - 1;
+  const int xbase = a.vec ? 4 - (KW - 1) / 2 : 0;   // LDS column of image x0 - padW
   const int plane_sz = THp * TWp;            // one channel of one plane in LDS
   const int CS = a.TN * plane_sz;            // channel stride in Xs
   float* Xs = smem;
@@ -65,12 +74,13 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
   const int pg = tile / a.tiles_y;
   const int plane0 = pg * a.TN;
   const int y0 = ty_i * a.TH, x0 = tx_i * a.TW;
+  const int co0 = blockIdx.y * CBW;
   if (a.plane_valid && a.TN == 1 && !a.plane_valid[plane0 / a.valid_div]) return;
 
   const int tapT = blockIdx.z;               // transposed-conv tap (0 otherwise)
-  const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp;
+  const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp + co0;
 
-  // per-lane LDS offset of each of this wave's pixels (B operand), -1 = masked
+  // per-lane LDS offset of each of this wave's pixels (B operand)
   const int tile_px = a.TN * a.TH * a.TW;
   int poff[PB];
 #pragma unroll
@@ -79,7 +89,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     if (q < tile_px) {
       const int n = q / (a.TH * a.TW), r = q - n * (a.TH * a.TW);
       const int ty = r / a.TW, tx = r - ty * a.TW;
-      poff[pb] = n * plane_sz + ty * TWp + tx;
+      poff[pb] = n * plane_sz + ty * TWp + tx + xbase;
     } else {
       poff[pb] = 0;                          // reads valid LDS, result never stored
     }
@@ -96,46 +106,109 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
   const int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
   const int HW = a.H * a.W;
   const int nrows = a.CC * a.TN * THp;
+  const int rows_per_ch = a.TN * THp;
+
+  // margins of the vector layout are never written by the per-chunk staging: clear once
+  if (a.vec) {
+    const int total = a.CC * CS;
+    for (int e = t; e < total; e += 256) Xs[e] = 0.0f;
+  }
 
   for (int c0 = 0; c0 < a.cinp; c0 += a.CC) {
     __syncthreads();
-    // ---- stage the halo tile: one (channel, plane, row) per wave iteration, lanes along x
-    for (int row = wave; row < nrows; row += 4) {
-      const int ci = row / (a.TN * THp);
-      const int rem = row - ci * (a.TN * THp);
-      const int n = rem / THp, ry = rem - n * THp;
-      const int c = c0 + ci, plane = plane0 + n, y = y0 + ry - padH;
-      const bool row_ok = c < a.cin && plane < a.planes && y >= 0 && y < a.H;
-      const float* g = row_ok ? a.src + (size_t(plane) * a.cin + c) * HW + size_t(y) * a.W : a.src;
-      float* d = Xs + ci * CS + n * plane_sz + ry * TWp;
-      for (int col = lane; col < TWp; col += 64) {
-        const int x = x0 + col - padW;
-        d[col] = (row_ok && x >= 0 && x < a.W) ? g[x] : 0.0f;
+    if (a.vec) {
+      // full-width tile, W % 4 == 0: image rows are contiguous 16-byte-aligned runs
+      const int qpr = a.W >> 2;                       // quads per row
+      const int nitems = nrows * qpr;
+      for (int it0 = t; it0 < nitems; it0 += 256 * kStageU) {
+        float4 v[kStageU];
+        int dst[kStageU];
+        bool ok[kStageU];
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u) {
+          const int it = it0 + 256 * u;
+          const bool live = it < nitems;
+          const int itc = live ? it : 0;
+          const int row = itc / qpr, q = itc - row * qpr;
+          const int ci = row / rows_per_ch;
+          const int rem = row - ci * rows_per_ch;
+          const int n = rem / THp, ry = rem - n * THp;
+          const int c = c0 + ci, plane = plane0 + n, y = y0 + ry - padH;
+          ok[u] = live && c < a.cin && plane < a.planes && y >= 0 && y < a.H;
+          dst[u] = live ? ci * CS + n * plane_sz + ry * TWp + 4 + 4 * q : -1;
+          const size_t off = ok[u] ? (size_t(plane) * a.cin + c) * HW + size_t(y) * a.W + 4 * q : 0;
+          v[u] = *reinterpret_cast<const float4*>(a.src + off);
+        }
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u)
+          if (dst[u] >= 0)
+            *reinterpret_cast<float4*>(Xs + dst[u]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      // generic path (narrow / odd-width maps): element-wise, halo written explicitly
+      const int nitems = nrows * TWp;
+      for (int it0 = t; it0 < nitems; it0 += 256 * kStageS) {
+        float v[kStageS];
+        int dst[kStageS];
+        bool ok[kStageS];
+#pragma unroll
+        for (int u = 0; u < kStageS; ++u) {
+          const int it = it0 + 256 * u;
+          const bool live = it < nitems;
+          const int itc = live ? it : 0;
+          const int row = itc / TWp, col = itc - row * TWp;
+          const int ci = row / rows_per_ch;
+          const int rem = row - ci * rows_per_ch;
+          const int n = rem / THp, ry = rem - n * THp;
+          const int c = c0 + ci, plane = plane0 + n, y = y0 + ry - padH, x = x0 + col - padW;
+          ok[u] = live && c < a.cin && plane < a.planes && y >= 0 && y < a.H && x >= 0 && x < a.W;
+          dst[u] = live ? itc + ci * (CS - rows_per_ch * TWp) : -1;   // = ci*CS + n*plane_sz + ry*TWp + col
+          const size_t off = ok[u] ? (size_t(plane) * a.cin + c) * HW + size_t(y) * a.W + x : 0;
+          v[u] = a.src[off];
+        }
+#pragma unroll
+        for (int u = 0; u < kStageS; ++u)
+          if (dst[u] >= 0) Xs[dst[u]] = ok[u] ? v[u] : 0.0f;
       }
     }
-    // ---- stage the weight slice (contiguous in the packed layout; zero beyond cinp)
+    // ---- weight slice: rows (ci, tap) of CBW floats at stride coutp; zero beyond cinp
     {
-      const int nw = a.CC * KK * a.coutp;
-      const int avail = (a.cinp - c0) * KK * a.coutp;
+      constexpr int QPR = CBW / 4;
+      const int nitems = a.CC * KK * QPR;
+      const int avail_rows = (a.cinp - c0) * KK;
       const float* gw = wts + size_t(c0) * KK * a.coutp;
-      for (int e = t * 4; e < nw; e += 1024) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < avail) v = *reinterpret_cast<const float4*>(gw + e);
-        *reinterpret_cast<float4*>(Ws + e) = v;
+      for (int it0 = t; it0 < nitems; it0 += 256 * kStageU) {
+        float4 v[kStageU];
+        int dst[kStageU];
+        bool ok[kStageU];
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u) {
+          const int it = it0 + 256 * u;
+          const bool live = it < nitems;
+          const int itc = live ? it : 0;
+          const int row = itc / QPR, q = itc - row * QPR;
+          ok[u] = live && row < avail_rows;
+          dst[u] = live ? itc * 4 : -1;
+          v[u] = *reinterpret_cast<const float4*>(gw + (ok[u] ? size_t(row) * a.coutp + 4 * q : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u)
+          if (dst[u] >= 0)
+            *reinterpret_cast<float4*>(Ws + dst[u]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     __syncthreads();
     // ---- MFMA over the chunk
     for (int ci = 0; ci < a.CC; ci += 2) {
       const float* xs = Xs + (ci + half) * CS;
-      const float* ws = Ws + (ci + half) * KK * a.coutp + l31;
+      const float* ws = Ws + (ci + half) * KK * CBW + l31;
 #pragma unroll
       for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
           float av[CB], bv[PB];
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb) av[cb] = ws[(ky * KW + kx) * a.coutp + cb * 32];
+          for (int cb = 0; cb < CB; ++cb) av[cb] = ws[(ky * KW + kx) * CBW + cb * 32];
 #pragma unroll
           for (int pb = 0; pb < PB; ++pb) bv[pb] = xs[poff[pb] + ky * TWp + kx];
 #pragma unroll
@@ -169,7 +242,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < a.cout) {
           float v = acc[cb][pb][r] + bias[co];
           v = v * scale[co] + shift[co];
@@ -254,11 +327,8 @@ static int dispatch_tile(int CB, int PB, const ConvArgs& a, dim3 grid, size_t ld
     case 11: return launch_conv<KH, KW, 1, 1>(a, grid, lds, s);
     case 12: return launch_conv<KH, KW, 1, 2>(a, grid, lds, s);
     case 14: return launch_conv<KH, KW, 1, 4>(a, grid, lds, s);
-    case 21: return launch_conv<KH, KW, 2, 1>(a, grid, lds, s);
     case 22: return launch_conv<KH, KW, 2, 2>(a, grid, lds, s);
-    case 24: return launch_conv<KH, KW, 2, 4>(a, grid, lds, s);
     case 41: return launch_conv<KH, KW, 4, 1>(a, grid, lds, s);
-    case 42: return launch_conv<KH, KW, 4, 2>(a, grid, lds, s);
     default: return FVP_ELIMIT;
   }
 }
@@ -308,13 +378,19 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   }
   a.OH = op.h * a.osy;
   a.OW = op.w * a.osx;
-  const int CB = op.coutp / 32;
-  if (CB != 1 && CB != 2 && CB != 4) return FVP_ELIMIT;
-  // pixels per plane decide PB (PB*128 pixels per workgroup)
+  const int CBfull = op.coutp / 32;
+  if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
+  // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
+  // Large grids keep all couts in one workgroup (input tile staged once); small grids split
+  // couts over blockIdx.y and shrink the pixel tile so that more CUs get work.
   const int hw = op.h * op.w;
-  int PB = CB == 1 ? 4 : (CB == 2 ? 2 : 1);   // CB*PB = 4 accumulator tiles: ~141 registers, 3 waves/SIMD
-  while (PB > 1 && PB * 128 > hw * (planes > 0 ? planes : 1)) PB >>= 1;
-  if (hw * planes < 128) PB = 1;
+  const long px_total = long(hw) * planes;
+  int CB = CBfull, PB = 4 / CBfull;
+  if (px_total / (128 * PB) < 512) {
+    CB = 1;
+    PB = 4;
+    while (PB > 1 && (px_total + 128 * PB - 1) / (128 * PB) * CBfull < 512) PB >>= 1;
+  }
   const int TP = PB * 128;
   if (hw <= TP) {                       // whole planes per tile
     a.TW = op.w;
@@ -333,14 +409,16 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   a.tiles_y = ceil_div(op.h, a.TH);
   const int pgroups = ceil_div(planes, a.TN);
   // channel chunk: largest even CC that fits the LDS budget
-  const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * (a.TW + kw - 1) + size_t(kh) * kw * op.coutp) * sizeof(float);
+  a.vec = (a.TW == op.w && op.w % 4 == 0) ? 1 : 0;
+  const int twp = a.vec ? a.TW + 8 : a.TW + kw - 1;
+  const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * twp + size_t(kh) * kw * 32 * CB) * sizeof(float);
   int CC = int((kLdsBudget - 16) / per_ch) & ~1;
   if (CC > op.cinp) CC = op.cinp;
   if (CC < 2) return FVP_ELIMIT;
   a.CC = CC;
-  const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * (a.TW + kw - 1) + 3) & ~size_t(3);
-  const size_t lds = (xs_floats + size_t(CC) * kh * kw * op.coutp) * sizeof(float);
-  dim3 grid(a.tiles_x * a.tiles_y * pgroups, 1, a.ntapT);
+  const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * twp + 3) & ~size_t(3);
+  const size_t lds = (xs_floats + size_t(CC) * kh * kw * 32 * CB) * sizeof(float);
+  dim3 grid(a.tiles_x * a.tiles_y * pgroups, CBfull / CB, a.ntapT);
   // algorithmic FLOPs (2*MAC on the true channel counts)
   const double taps = tr ? double(a.ntapT) : double(op.kh * op.kw);
   ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * hw * planes);

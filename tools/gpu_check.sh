@@ -24,5 +24,5 @@ PY
 done
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-prof > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
-find "$out/prof_${tag}" -name "*kernel_stats*.csv" | head -1 | xargs -r head -30
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-prof > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
+find "$out/prof_${tag}" -name "*kernel_stats*.csv" | head -1 | xargs -r head -40 | cut -c1-220
