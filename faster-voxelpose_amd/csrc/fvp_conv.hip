@@ -20,6 +20,8 @@
 // BatchNorm (eval), bias, residual add and ReLU are fused into the store epilogue.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fvp_common.h"
 
 namespace fvp {
@@ -44,6 +46,8 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int CC;             // input channels per LDS chunk (even)
   int flags;
+  int ablate;         // diagnostics only (FVP_CONV_ABLATE): 1 skip input staging, 2 skip weight staging,
+                      // 4 skip the MFMA loop, 8 skip the epilogue stores
   int vec;            // 1: full-width tile with W % 4 == 0 -> 16-byte staging, margin layout
   int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
   int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
@@ -116,7 +120,8 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
 
   for (int c0 = 0; c0 < a.cinp; c0 += a.CC) {
     __syncthreads();
-    if (a.vec) {
+    if (a.ablate & 1) {
+    } else if (a.vec) {
       // full-width tile, W % 4 == 0: image rows are contiguous 16-byte-aligned runs
       const int qpr = a.W >> 2;                       // quads per row
       const int nitems = nrows * qpr;
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
       }
     }
     // ---- weight slice: rows (ci, tap) of CBW floats at stride coutp; zero beyond cinp
-    {
+    if (!(a.ablate & 2)) {
       constexpr int QPR = CBW / 4;
       const int nitems = a.CC * KK * QPR;
       const int avail_rows = (a.cinp - c0) * KK;
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     }
     __syncthreads();
     // ---- MFMA over the chunk
-    for (int ci = 0; ci < a.CC; ci += 2) {
+    for (int ci = (a.ablate & 4) ? a.CC : 0; ci < a.CC; ci += 2) {
       const float* xs = Xs + (ci + half) * CS;
       const float* ws = Ws + (ci + half) * KK * CBW + l31;
 #pragma unroll
@@ -222,6 +227,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
   }
 
   // ---- epilogue: bias, BN scale/shift, residual, ReLU; coalesced NCHW stores
+  if (a.ablate & 8) return;
   const float* bias = a.epi;
   const float* scale = a.epi + a.coutp;
   const float* shift = a.epi + 2 * a.coutp;
@@ -342,7 +348,14 @@ static int dispatch_conv(int kh, int kw, int CB, int PB, const ConvArgs& a, dim3
   return FVP_ELIMIT;
 }
 
-static constexpr size_t kLdsBudget = 64 * 1024;
+static size_t env_size(const char* name, size_t dflt) {
+  const char* v = getenv(name);
+  return v ? size_t(atol(v)) : dflt;
+}
+// tuning knobs (diagnostics): FVP_CONV_LDS_KB, FVP_CONV_ABLATE, FVP_CONV_PB
+static const size_t kLdsBudget = env_size("FVP_CONV_LDS_KB", 64) * 1024;
+static const int kAblate = int(env_size("FVP_CONV_ABLATE", 0));
+static const int kForcePB = int(env_size("FVP_CONV_PB", 0));
 
 // Tile selection: all couts per workgroup (CB = coutp/32), PB so that CB*PB <= 8 accumulator
 // tiles per wave, the tile shaped to cover full image rows where possible.
@@ -391,6 +404,8 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
     PB = 4;
     while (PB > 1 && (px_total + 128 * PB - 1) / (128 * PB) * CBfull < 512) PB >>= 1;
   }
+  if (kForcePB && CB * kForcePB <= 4) PB = kForcePB;
+  a.ablate = kAblate;
   const int TP = PB * 128;
   if (hw <= TP) {                       // whole planes per tile
     a.TW = op.w;
