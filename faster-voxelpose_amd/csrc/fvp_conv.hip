@@ -20,7 +20,9 @@
 // BatchNorm (eval), bias, residual add and ReLU are fused into the store epilogue.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fvp_common.h"
 
@@ -37,6 +39,7 @@ struct ConvArgs {
   const float* wts;   // packed [cinp][KK][coutp] (+ tap-major blocks for transposed conv)
   const float* epi;   // bias | scale | shift, each coutp
   const uint8_t* plane_valid;
+  const float* zeros; // >= 16 bytes of zeros in device memory (head of the params blob)
   int valid_div;
   int planes, cin, cinp, cout, coutp;
   int H, W;           // input spatial size
@@ -48,10 +51,62 @@ struct ConvArgs {
   int flags;
   int ablate;         // diagnostics only (FVP_CONV_ABLATE): 1 skip input staging, 2 skip weight staging,
                       // 4 skip the MFMA loop, 8 skip the epilogue stores
+  int dma;            // 1: k_conv_dma (pipelined LDS-DMA staging), needs vec
   int vec;            // 1: full-width tile with W % 4 == 0 -> 16-byte staging, margin layout
   int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
   int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
 };
+
+// ---------------------------------------------------------------------------------------------
+// Shared epilogue: bias, BN scale/shift, residual, ReLU; coalesced NCHW stores.  Residual values
+// are fetched with unconditional (address-clamped) loads, 16 per accumulator tile, before any
+// arithmetic, so they cost one memory latency per tile instead of one per element.
+template <int CB, int PB, bool HAS_RES>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[CB][PB], int wave, int l31, int half,
+                                              int plane0, int y0, int x0, int co0, int tapT) {
+  const float* bias = a.epi;
+  const float* scale = a.epi + a.coutp;
+  const float* shift = a.epi + 2 * a.coutp;
+  const int OHW = a.OH * a.OW;
+  const int dy = (a.ntapT > 1) ? tapT / a.tapT_w : 0, dx = (a.ntapT > 1) ? tapT % a.tapT_w : 0;
+  const bool relu = a.flags & FVP_EPI_RELU;
+  const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
+  const int tile_px = a.TN * a.TH * a.TW;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int q = (wave * PB + pb) * 32 + l31;
+    const int qc = q < tile_px ? q : 0;
+    const int n = qc / (a.TH * a.TW), r2 = qc - n * (a.TH * a.TW);
+    const int ty = r2 / a.TW, tx = r2 - ty * a.TW;
+    const int plane = plane0 + n, y = y0 + ty, x = x0 + tx;
+    const bool pix_ok = q < tile_px && plane < a.planes && y < a.H && x < a.W;
+    const size_t opix = pix_ok ? size_t(y * a.osy + dy) * a.OW + (x * a.osx + dx) : 0;
+    const size_t pbase = pix_ok ? size_t(plane) * a.cout : 0;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      float rv[16];
+      unsigned o[16];
+      bool ok[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        ok[r] = pix_ok && co < a.cout;
+        o[r] = unsigned((pbase + (ok[r] ? co : 0)) * OHW + opix);
+        if (HAS_RES) rv[r] = a.res[o[r]];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // < coutp: epi vectors are padded
+        float v = acc[cb][pb][r] + bias[co];
+        v = v * scale[co] + shift[co];
+        if (HAS_RES && !res_after) v += rv[r];
+        if (relu) v = fmaxf(v, 0.0f);
+        if (HAS_RES && res_after) v += rv[r];
+        if (ok[r]) a.dst[o[r]] = v;
+      }
+    }
+  }
+}
 
 // Branch-free staging helpers: every thread computes kU addresses, issues kU independent
 // loads (out-of-range items read a valid dummy address and are masked afterwards -- a branch
@@ -226,40 +281,232 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     }
   }
 
-  // ---- epilogue: bias, BN scale/shift, residual, ReLU; coalesced NCHW stores
   if (a.ablate & 8) return;
+  if (a.flags & FVP_EPI_RES)
+    conv_epilogue<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, x0, co0, tapT);
+  else
+    conv_epilogue<CB, PB, false>(a, acc, wave, l31, half, plane0, y0, x0, co0, tapT);
+}
+
+// Wide epilogue for stride-1 outputs of the pipelined kernel: each 32x32 accumulator tile goes
+// through a 4 KB per-wave LDS scratch so that a lane ends up with 4 consecutive pixels of one
+// channel -> dwordx4 residual loads and dwordx4 stores in 128-byte runs (the MFMA layout gives a
+// lane 16 different channels of ONE pixel, i.e. 4-byte stores).
+template <int CB, int PB, bool HAS_RES>
+__device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&acc)[CB][PB], float* scratch, int wave,
+                                                   int lane, int plane0, int y0, int co0) {
   const float* bias = a.epi;
   const float* scale = a.epi + a.coutp;
   const float* shift = a.epi + 2 * a.coutp;
-  const int OHW = a.OH * a.OW;
-  const int dy = (a.ntapT > 1) ? tapT / a.tapT_w : 0, dx = (a.ntapT > 1) ? tapT % a.tapT_w : 0;
-  const bool relu = a.flags & FVP_EPI_RELU, has_res = a.flags & FVP_EPI_RES;
+  const bool relu = a.flags & FVP_EPI_RELU;
   const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
+  const int tile_px = a.TN * a.TH * a.TW;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int HW = a.H * a.W;
+  float* sc = scratch + wave * 1024;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[cb][pb][r];
+      __syncthreads();
+      float4 v[4], rv[4];
+      unsigned off[4];
+      bool ok[4];
+      int co[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        const int col = i >> 3, qd = i & 7;
+        v[j] = *reinterpret_cast<const float4*>(sc + col * 32 + qd * 4);
+        co[j] = co0 + cb * 32 + col;
+        const int q = (wave * PB + pb) * 32 + qd * 4;
+        const int qc = q < tile_px ? q : 0;
+        const int n = qc / (a.TH * a.TW), r2 = qc - n * (a.TH * a.TW);
+        const int ty = r2 / a.TW, tx = r2 - ty * a.TW;
+        const int plane = plane0 + n, y = y0 + ty;
+        ok[j] = q < tile_px && plane < a.planes && y < a.H && co[j] < a.cout;
+        off[j] = ok[j] ? unsigned((plane * a.cout + co[j]) * HW + y * a.W + tx) : 0u;
+        if (HAS_RES) rv[j] = *reinterpret_cast<const float4*>(a.res + off[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b = bias[co[j]], sc_ = scale[co[j]], sh = shift[co[j]];
+        float o[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        const float rr[4] = {HAS_RES ? rv[j].x : 0.f, HAS_RES ? rv[j].y : 0.f, HAS_RES ? rv[j].z : 0.f,
+                             HAS_RES ? rv[j].w : 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = (o[e] + b) * sc_ + sh;
+          if (HAS_RES && !res_after) x += rr[e];
+          if (relu) x = fmaxf(x, 0.0f);
+          if (HAS_RES && res_after) x += rr[e];
+          o[e] = x;
+        }
+        if (ok[j]) *reinterpret_cast<float4*>(a.dst + off[j]) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined conv for full-width tiles with W % 4 == 0 (every 2-D layer of the three nets):
+// chunk k+1 is copied HBM/L2 -> LDS by the LDS-DMA (global_load_lds, 16 B per lane, no VGPRs)
+// while the matrix cores work on chunk k; two LDS buffers, one barrier per chunk.
+//   Xs[buf][CC][TN][TH+KH-1][W]   dense rows (the DMA writes base + lane*16); the horizontal halo
+//                                  is a per-lane bit mask applied to the B operand, the vertical
+//                                  halo / channel padding / missing planes read a zero page
+//   Ws[buf][CC][KH*KW][32*CB]
+template <int KH, int KW, int CB, int PB>
+__global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  constexpr int KK = KH * KW;
+  constexpr int CBW = 32 * CB;
+  constexpr int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int THp = a.TH + KH - 1, W = a.W;
+  const int plane_sz = THp * W;
+  const int CS = a.TN * plane_sz;
+  const int xs_sz = a.CC * CS, ws_sz = a.CC * KK * CBW, buf_sz = xs_sz + ws_sz;   // floats, all % 4 == 0
+
+  int tile = blockIdx.x;
+  const int ty_i = tile % a.tiles_y;
+  const int pg = tile / a.tiles_y;
+  const int plane0 = pg * a.TN;
+  const int y0 = ty_i * a.TH;
+  const int co0 = blockIdx.y * CBW;
+  if (a.plane_valid && a.TN == 1 && !a.plane_valid[plane0 / a.valid_div]) return;
+  const int tapT = blockIdx.z;
+  const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp + co0;
+
+  const int tile_px = a.TN * a.TH * a.TW;
+  int poff[PB];
+  unsigned xmask[PB];
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int q = (wave * PB + pb) * 32 + l31;
-    if (q >= tile_px) continue;
-    const int n = q / (a.TH * a.TW), r2 = q - n * (a.TH * a.TW);
-    const int ty = r2 / a.TW, tx = r2 - ty * a.TW;
-    const int plane = plane0 + n, y = y0 + ty, x = x0 + tx;
-    if (plane >= a.planes || y >= a.H || x >= a.W) continue;
-    const size_t opix = size_t(y * a.osy + dy) * a.OW + (x * a.osx + dx);
+    const int qc = q < tile_px ? q : 0;
+    const int n = qc / (a.TH * W), r = qc - n * (a.TH * W);
+    const int ty = r / W, tx = r - ty * W;
+    poff[pb] = n * plane_sz + ty * W + tx - padW;
+    unsigned m = 0;
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
+    for (int kx = 0; kx < KW; ++kx) m |= (tx + kx - padW >= 0 && tx + kx - padW < W) ? (1u << kx) : 0u;
+    xmask[pb] = m;
+  }
+
+  f32x16 acc[CB][PB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a.cout) {
-          float v = acc[cb][pb][r] + bias[co];
-          v = v * scale[co] + shift[co];
-          const size_t o = (size_t(plane) * a.cout + co) * OHW + opix;
-          if (has_res && !res_after) v += a.res[o];
-          if (relu) v = fmaxf(v, 0.0f);
-          if (has_res && res_after) v += a.res[o];
-          a.dst[o] = v;
-        }
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.0f;
+
+  const int HW = a.H * W;
+  const int qpr = W >> 2;
+  const int rows_per_ch = a.TN * THp;
+  const int nin = a.CC * rows_per_ch * qpr;          // 16-byte items of the input tile
+  const int nwq = a.CC * KK * (CBW / 4);             // 16-byte items of the weight slice
+  const int nchunks = (a.cinp + a.CC - 1) / a.CC;
+
+  auto stage = [&](int k, int buf) {
+    float* xs = smem + 4 + buf * buf_sz;
+    float* ws = xs + xs_sz;
+    const int c0 = k * a.CC;
+    for (int g = wave; g * 64 < nin; g += 4) {
+      const int it = g * 64 + lane;
+      if (it < nin) {
+        const int row = it / qpr, q = it - row * qpr;
+        const int ci = row / rows_per_ch;
+        const int rem = row - ci * rows_per_ch;
+        const int n = rem / THp, ry = rem - n * THp;
+        const int c = c0 + ci, plane = plane0 + n, y = y0 + ry - padH;
+        const bool ok = c < a.cin && plane < a.planes && y >= 0 && y < a.H;
+        const float* src = ok ? a.src + (size_t(plane) * a.cin + c) * HW + size_t(y) * W + 4 * q : a.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, 0);
       }
     }
+    const int avail_rows = (a.cinp - c0) * KK;
+    const float* gw = wts + size_t(c0) * KK * a.coutp;
+    for (int g = wave; g * 64 < nwq; g += 4) {
+      const int it = g * 64 + lane;
+      if (it < nwq) {
+        const int row = it / (CBW / 4), q = it - row * (CBW / 4);
+        const float* src = row < avail_rows ? gw + size_t(row) * a.coutp + 4 * q : a.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ws + g * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  if (!(a.ablate & 3)) stage(0, 0);
+  __syncthreads();
+  for (int k = 0; k < nchunks; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < nchunks && !(a.ablate & 3)) stage(k + 1, buf ^ 1);
+    const float* Xs = smem + 4 + buf * buf_sz;
+    const float* Ws = Xs + xs_sz;
+    // Software-pipelined operand fetch: the LDS reads of step s+1 (one tap of one channel pair:
+    // CB A-words + PB B-words) are issued before the CB*PB MFMAs of step s; sched_barriers pin
+    // that order (left alone, hipcc sinks every ds_read next to its MFMA and each MFMA eats a
+    // full LDS latency).  Two register sets; KK is odd for every kernel shape, so consecutive
+    // channel pairs alternate the starting set (template parameter P).
+    float av[2][CB], bv[2][PB];
+    auto fetch = [&](int set, int ci, int tap) {
+      const int cic = ci < a.CC ? ci : a.CC - 2;              // last prefetch of a chunk: harmless re-read
+      const float* xs = Xs + (cic + half) * CS;
+      const float* ws = Ws + (cic + half) * KK * CBW + l31;
+      const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) av[set][cb] = ws[tap * CBW + cb * 32];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) bv[set][pb] = xs[poff[pb] + ky * W + kx];
+    };
+    auto block = [&](auto parity, int ci) {
+      constexpr int P = decltype(parity)::value;
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int cur = (P + tap) & 1, nxt = cur ^ 1;
+        if (tap + 1 < KK) fetch(nxt, ci, tap + 1);
+        else fetch(nxt, ci + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kx = tap % KW;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+          const float b = (KW == 1 || ((xmask[pb] >> kx) & 1u)) ? bv[cur][pb] : 0.0f;
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+            acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][cb], b, acc[cb][pb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (!(a.ablate & 4)) {
+      fetch(0, 0, 0);
+      for (int ci = 0; ci < a.CC; ci += 4) {
+        block(std::integral_constant<int, 0>{}, ci);
+        if (ci + 2 < a.CC) block(std::integral_constant<int, 1>{}, ci + 2);
+      }
+    }
+    __syncthreads();
+  }
+  if (a.ablate & 8) return;
+  if (a.ntapT > 1 || (a.ablate & 16)) {          // transposed conv: strided outputs, scalar stores
+    if (a.flags & FVP_EPI_RES)
+      conv_epilogue<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
+    else
+      conv_epilogue<CB, PB, false>(a, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
+  } else if (a.flags & FVP_EPI_RES) {
+    conv_epilogue_wide<CB, PB, true>(a, acc, smem + 4, wave, lane, plane0, y0, co0);
+  } else {
+    conv_epilogue_wide<CB, PB, false>(a, acc, smem + 4, wave, lane, plane0, y0, co0);
   }
 }
 
@@ -321,8 +568,13 @@ k_pack_conv(const float* __restrict__ w, const float* __restrict__ b, const floa
 
 template <int KH, int KW, int CB, int PB>
 static int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto k = &k_conv<KH, KW, CB, PB>;
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  if (a.dma) {
+    auto k = &k_conv_dma<KH, KW, CB, PB>;
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  } else {
+    auto k = &k_conv<KH, KW, CB, PB>;
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  }
   return launch_status();
 }
 
@@ -356,6 +608,7 @@ static size_t env_size(const char* name, size_t dflt) {
 static const size_t kLdsBudget = env_size("FVP_CONV_LDS_KB", 64) * 1024;
 static const int kAblate = int(env_size("FVP_CONV_ABLATE", 0));
 static const int kForcePB = int(env_size("FVP_CONV_PB", 0));
+static const int kNoDma = int(env_size("FVP_CONV_NO_DMA", 0));
 
 // Tile selection: all couts per workgroup (CB = coutp/32), PB so that CB*PB <= 8 accumulator
 // tiles per wave, the tile shaped to cover full image rows where possible.
@@ -391,6 +644,7 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   }
   a.OH = op.h * a.osy;
   a.OW = op.w * a.osx;
+  if (double(planes) * std::max(op.cin, op.cout) * a.OH * a.OW >= 2147483648.0) return FVP_ELIMIT;
   const int CBfull = op.coutp / 32;
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
   // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
@@ -425,14 +679,20 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   const int pgroups = ceil_div(planes, a.TN);
   // channel chunk: largest even CC that fits the LDS budget
   a.vec = (a.TW == op.w && op.w % 4 == 0) ? 1 : 0;
-  const int twp = a.vec ? a.TW + 8 : a.TW + kw - 1;
+  a.dma = (a.vec && !kNoDma) ? 1 : 0;
+  a.zeros = params;
+  const int twp = a.dma ? a.TW : (a.vec ? a.TW + 8 : a.TW + kw - 1);
   const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * twp + size_t(kh) * kw * 32 * CB) * sizeof(float);
-  int CC = int((kLdsBudget - 16) / per_ch) & ~1;
+  // the pipelined kernel keeps two chunks in LDS
+  int CC = int((kLdsBudget - 32) / (per_ch * (a.dma ? 2 : 1))) & ~1;
   if (CC > op.cinp) CC = op.cinp;
   if (CC < 2) return FVP_ELIMIT;
+  for (int d = CC; d >= 2 && d * 2 > CC; d -= 2)      // avoid a ragged last chunk when a close divisor exists
+    if (op.cinp % d == 0) { CC = d; break; }
   a.CC = CC;
   const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * twp + 3) & ~size_t(3);
-  const size_t lds = (xs_floats + size_t(CC) * kh * kw * 32 * CB) * sizeof(float);
+  const size_t lds = a.dma ? std::max<size_t>(16 + 2 * per_ch * CC, 16 + 16384)
+                           : (xs_floats + size_t(CC) * kh * kw * 32 * CB) * sizeof(float);
   dim3 grid(a.tiles_x * a.tiles_y * pgroups, CBfull / CB, a.ntapT);
   // algorithmic FLOPs (2*MAC on the true channel counts)
   const double taps = tr ? double(a.ntapT) : double(op.kh * op.kw);

@@ -173,8 +173,9 @@ class StackSpec:
         return x
 
     def finalize(self):
-        """Assign packed-parameter offsets and build the ctypes op array."""
-        off = 0
+        """Assign packed-parameter offsets and build the ctypes op array.  The first 64 floats of
+        the blob stay zero: the conv kernel's LDS-DMA reads them for padding rows."""
+        off = 64
         arr = (capi.FvpConvOp * len(self.ops))()
         for i, o in enumerate(self.ops):
             cinp = _round_up(o["cin"], 2)

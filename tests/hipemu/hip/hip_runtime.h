@@ -132,6 +132,16 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 
+// LDS-DMA: wave-uniform LDS base + lane * size, per-lane global source
+static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* l,
+                               unsigned size, int off, unsigned) {
+  char* dst = (char*)(void*)l + off + size_t(hipemu::cur->lane) * size;
+  memcpy(dst, (const char*)(const void*)g + off, size);
+}
+#define __builtin_amdgcn_global_load_lds hipemu_glds
+
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
 // ---- scalar intrinsics -------------------------------------------------------------------
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
