@@ -218,87 +218,216 @@ k_triplane_max(const float* __restrict__ cubes, float* __restrict__ planes, int 
 
 // ---------------------------------------------------------------------------------------------
 // Fused fast path: sample every voxel of the person's window and emit the three maxima
-// without writing the cube.  Workgroup = (person, chunk of 256/C rows of y); thread = one
-// (y,z) cell, lanes along z; loop over x.
+// without writing the cube.
+//
+// The gather is bound by the texture-addresser / L1 line rate (GRBM_TA_BUSY 95 % in the first
+// version, which gave every lane a whole 64-byte pixel = 4 dwordx4 loads touching 64 different
+// cache lines per instruction).  Here four consecutive lanes share one voxel: lane q of the quad
+// loads channels 4q..4q+3 of each tap, so one dwordx4 instruction covers 16 voxels x 64
+// contiguous bytes (4x fewer lines per instruction).  The projection arithmetic is shared inside
+// the quad: lane q projects view q and the tap descriptors are broadcast with DPP quad_perm.
+//
+// Workgroup = (person, 256 (y,z) cells) x 4 lanes = 1024 threads; lanes of a wave: 16 consecutive
+// z x 4 channel quads; loop over x inside the thread.
 //   yz[y][z] = max_x : running max in registers, owned by this workgroup -> plain store
-//   xy[x][y] = max_z : segmented wave-shuffle reduction over the row's lanes
-//   xz[x][z] = max_y : LDS reduction over the workgroup's rows, then integer atomicMax across
-//                      workgroups (values are clamped to [0,1] => non-negative => the int
-//                      ordering equals the float ordering; planes are pre-zeroed)
-template <int NV>
-__global__ void __launch_bounds__(256)
+//   xy[x][y] = max_z : shuffle over the 16 z-lanes of a wave, then LDS across the row's waves
+//   xz[x][z] = max_y : LDS over the workgroup's rows, then integer atomicMax across workgroups
+//                      (values are clamped to [0,1] => non-negative => int order == float order;
+//                      planes are pre-zeroed, so the result is order-independent and bit-equal
+//                      to the materialised path)
+// Workgroups are numbered so that all persons of one frame run on one XCD (block id mod 8 is the
+// XCD): an XCD's L2 then serves one frame's heatmaps instead of all of them.
+struct TapD {   // tap descriptor of one (voxel, view): 4 offsets, 4 weights, inside mask
+  int off[4];
+  float w[4];
+  int inside;
+};
+
+template <int SRC>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, SRC * 0x55, 0xf, 0xf, false);   // quad_perm [SRC,SRC,SRC,SRC]
+}
+template <int SRC>
+__device__ __forceinline__ TapD quad_bcast(const TapD& t) {
+  TapD r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r.off[k] = quad_bcast_i<SRC>(t.off[k]);
+    r.w[k] = __int_as_float(quad_bcast_i<SRC>(__float_as_int(t.w[k])));
+  }
+  r.inside = quad_bcast_i<SRC>(t.inside);
+  return r;
+}
+
+__device__ __forceinline__ TapD make_taps(const Cam& cm, const FvpGeom& g, float wx, float wy, float wz) {
+  float gx, gy;
+  project_norm(cm, g, wx, wy, wz, gx, gy);
+  const Taps t = bilinear_taps(gx, gy, g.W, g.H);
+  TapD d;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { d.off[k] = t.off[k]; d.w[k] = t.w[k]; }
+  d.inside = t.inside;
+  return d;
+}
+
+// acc[i] (+)= bilinear sample of channels ch0..ch0+3 (reference accumulation order: nw*w then fma)
+__device__ __forceinline__ void sample4(const float* __restrict__ cl, int JP, int ch0, const TapD& t, bool first,
+                                        float (&acc)[4]) {
+  float4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool in = (t.inside >> k) & 1;
+    v[k] = *reinterpret_cast<const float4*>(cl + size_t(in ? t.off[k] : 0) * JP + ch0);
+    if (!in) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float s[4] = {__fmul_rn(v[0].x, t.w[0]), __fmul_rn(v[0].y, t.w[0]), __fmul_rn(v[0].z, t.w[0]),
+                __fmul_rn(v[0].w, t.w[0])};
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    s[0] = __fmaf_rn(v[k].x, t.w[k], s[0]);
+    s[1] = __fmaf_rn(v[k].y, t.w[k], s[1]);
+    s[2] = __fmaf_rn(v[k].z, t.w[k], s[2]);
+    s[3] = __fmaf_rn(v[k].w, t.w[k], s[3]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = first ? s[i] : __fadd_rn(acc[i], s[i]);
+}
+
+template <int NVL>   // channel quads per lane: ceil(JP/16)
+__global__ void __launch_bounds__(1024)
 k_project_triplane(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
                    const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
                    const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
-                   const float* __restrict__ fz, int C, FvpGeom g, float* __restrict__ planes) {
-  __shared__ float sm[4 * NV][256];
-  const int p = blockIdx.y;
+                   const float* __restrict__ fz, int C, int nP, int chunks, int ppf, FvpGeom g,
+                   float* __restrict__ planes) {
+  __shared__ float sm_xz[4 * NVL * 4][256];       // [channel][cell]
+  __shared__ float sm_xy[16][4 * NVL * 4];        // [wave][channel]
+  // ---- block -> (person, chunk), frame-major per XCD when the frame count allows it
+  int p, chunk;
+  {
+    const int id = blockIdx.x;
+    const int bpf = ppf * chunks;                 // blocks per frame
+    const int nframes = nP / ppf;
+    if (nframes % 8 == 0) {
+      const int xcd = id & 7, j = id >> 3;
+      const int frame = xcd + 8 * (j / bpf), r = j % bpf;
+      p = frame * ppf + r / chunks;
+      chunk = r % chunks;
+    } else {
+      p = id / chunks;
+      chunk = id % chunks;
+    }
+  }
   if (person_valid && !person_valid[p]) return;
   const int* bx = boxes + p * 9;
   const int tl0 = bx[0], tl1 = bx[1], tl2 = bx[2];
   const int s0 = bx[3], s1 = bx[4], s2 = bx[5], e0 = bx[6], e1 = bx[7], e2 = bx[8];
   if (s0 >= e0 || s1 >= e1 || s2 >= e2) return;
-  const int t = threadIdx.x, J = g.J, CC = C * C;
-  const int rows = 256 / C > 0 ? 256 / C : 1;           // y rows per workgroup (C <= 256)
-  const int seg = C < 64 ? C : 64;                      // lanes sharing one (x,y) row in a wave
-  const int cell = blockIdx.x * 256 + t;                // (y,z) cell of this thread
+  const int t = threadIdx.x, q = t & 3, lane = t & 63, wave = t >> 6;
+  const int J = g.J, JP = g.JP, CC = C * C;
+  const int rows = 256 / C > 0 ? 256 / C : 1;
+  const int cell_l = t >> 2;                       // 0..255 within the workgroup
+  const int cell = chunk * 256 + cell_l;
   const int y = cell / C, z = cell - y * C;
-  const int y_first = (blockIdx.x * 256) / C;
-  // whole chunk outside the y window -> nothing to do (planes are pre-zeroed)
-  if (tl1 + y_first >= e1 || tl1 + y_first + rows - 1 < s1) return;
+  const int y_first = (chunk * 256) / C;
+  if (tl1 + y_first >= e1 || tl1 + y_first + rows - 1 < s1) return;   // chunk outside the y window
   const int gy_ = tl1 + y, gz_ = tl2 + z;
-  const bool yz_in = gy_ >= s1 && gy_ < e1 && gz_ >= s2 && gz_ < e2;
+  const bool yz_in = y < C && gy_ >= s1 && gy_ < e1 && gz_ >= s2 && gz_ < e2;
   const int b = person_frame[p];
-  const float* frame = heat_cl + size_t(b) * g.V * g.H * g.W * (4 * NV);
+  const size_t view_stride = size_t(g.H) * g.W * JP;
+  const float* frame = heat_cl + size_t(b) * g.V * view_stride;
   const Cam* cm = cams + size_t(frame_set[b]) * g.V;
   const float wy = yz_in ? fy[gy_] : 0.0f, wz = yz_in ? fz[gz_] : 0.0f;
   float* pxy = planes + (size_t(p) * 3 + 0) * J * CC;
   float* pxz = planes + (size_t(p) * 3 + 1) * J * CC;
   float* pyz = planes + (size_t(p) * 3 + 2) * J * CC;
-  float run[4 * NV];
+  const int wpr = C >= 16 ? C / 16 : 1;           // waves per y row
+  float run[NVL][4];
 #pragma unroll
-  for (int c = 0; c < 4 * NV; ++c) run[c] = 0.0f;
+  for (int n = 0; n < NVL; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) run[n][i] = 0.0f;
+  const float nv = float(g.V);
   const int lx0 = s0 - tl0, lx1 = e0 - tl0;
   for (int lx = lx0; lx < lx1; ++lx) {
-    float acc[4 * NV];
+    const float wx = fx[tl0 + lx];
+    float acc[NVL][4];
 #pragma unroll
-    for (int c = 0; c < 4 * NV; ++c) acc[c] = 0.0f;
-    if (yz_in) backproject_point<NV>(frame, cm, g, fx[tl0 + lx], wy, wz, acc);
+    for (int n = 0; n < NVL; ++n)
 #pragma unroll
-    for (int c = 0; c < 4 * NV; ++c) run[c] = fmaxf(run[c], acc[c]);
-    // xy: max over z within the row segment
+      for (int i = 0; i < 4; ++i) acc[n][i] = 0.0f;
+    // lane q projects view q; descriptors are shared inside the quad by DPP
+    TapD mine;
+    mine.inside = 0;
 #pragma unroll
-    for (int c = 0; c < 4 * NV; ++c) {
-      float m = acc[c];
-      for (int o = seg >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-      if (c < J && (t & (seg - 1)) == 0 && m > 0.0f) {
-        if (C <= 64) pxy[size_t(c) * CC + lx * C + y] = m;
-        else atomicMax(reinterpret_cast<int*>(&pxy[size_t(c) * CC + lx * C + y]), __float_as_int(m));
+    for (int k = 0; k < 4; ++k) { mine.off[k] = 0; mine.w[k] = 0.0f; }
+    if (yz_in && q < g.V) mine = make_taps(cm[q], g, wx, wy, wz);
+    auto add_view = [&](const TapD& tv, int v) {
+#pragma unroll
+      for (int n = 0; n < NVL; ++n) {
+        const int ch0 = 16 * n + 4 * q;
+        if (ch0 < JP) {
+          if (tv.inside) sample4(frame + v * view_stride, JP, ch0, tv, v == 0, acc[n]);
+          else if (v == 0) { acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f; }
+        }
+      }
+    };
+    { const TapD tv = quad_bcast<0>(mine); if (yz_in) add_view(tv, 0); }
+    if (g.V > 1) { const TapD tv = quad_bcast<1>(mine); if (yz_in) add_view(tv, 1); }
+    if (g.V > 2) { const TapD tv = quad_bcast<2>(mine); if (yz_in) add_view(tv, 2); }
+    if (g.V > 3) { const TapD tv = quad_bcast<3>(mine); if (yz_in) add_view(tv, 3); }
+    for (int v = 4; v < g.V; ++v)
+      if (yz_in) add_view(make_taps(cm[v], g, wx, wy, wz), v);
+#pragma unroll
+    for (int n = 0; n < NVL; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[n][i] = clampf(__fdiv_rn(acc[n][i], nv), 0.0f, 1.0f);
+        run[n][i] = fmaxf(run[n][i], acc[n][i]);
+      }
+    // ---- reductions
+    __syncthreads();                               // previous iteration's LDS readers are done
+#pragma unroll
+    for (int n = 0; n < NVL; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 16 * n + 4 * q + i;
+        sm_xz[c][cell_l] = acc[n][i];
+        float m = acc[n][i];
+        const int zw = C < 16 ? C : 16;            // z lanes of this row inside the wave
+        for (int o = (zw >> 1) * 4; o >= 4; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (C >= 16) { if ((lane >> 2) == 0) sm_xy[wave][c] = m; }
+        else if (((lane >> 2) & (zw - 1)) == 0 && c < J && y < C && m > 0.0f) pxy[size_t(c) * CC + lx * C + y] = m;
+      }
+    __syncthreads();
+    if (C >= 16) {                                 // xy: combine the waves of each row
+      const int nitem = rows * J;
+      if (t < nitem) {
+        const int r = t / J, c = t - r * J;
+        float m = sm_xy[r * wpr][c];
+        for (int k = 1; k < wpr; ++k) m = fmaxf(m, sm_xy[r * wpr + k][c]);
+        const int yy = y_first + r;
+        if (yy < C && m > 0.0f) pxy[size_t(c) * CC + lx * C + yy] = m;
       }
     }
-    // xz: max over this workgroup's rows through LDS, then across workgroups
-    if (rows > 1) {
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < 4 * NV; ++c) sm[c][t] = acc[c];
-      __syncthreads();
-      for (int item = t; item < J * C; item += 256) {
-        const int c = item / C, zz = item - c * C;
-        float m = sm[c][zz];
-        for (int r = 1; r < rows; ++r) m = fmaxf(m, sm[c][r * C + zz]);
-        if (m > 0.0f) atomicMax(reinterpret_cast<int*>(&pxz[size_t(c) * CC + lx * C + zz]), __float_as_int(m));
+    for (int item = t; item < J * C; item += 1024) {   // xz: max over this workgroup's rows
+      const int c = item / C, zz = item - c * C;
+      float m = sm_xz[c][zz];
+      for (int r = 1; r < rows; ++r) m = fmaxf(m, sm_xz[c][r * C + zz]);
+      if (m > 0.0f) {
+        if (chunks > 1) atomicMax(reinterpret_cast<int*>(&pxz[size_t(c) * CC + lx * C + zz]), __float_as_int(m));
+        else pxz[size_t(c) * CC + lx * C + zz] = m;
       }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4 * NV; ++c)
-        if (c < J && acc[c] > 0.0f)
-          atomicMax(reinterpret_cast<int*>(&pxz[size_t(c) * CC + lx * C + z]), __float_as_int(acc[c]));
     }
   }
   if (y < C) {
 #pragma unroll
-    for (int c = 0; c < 4 * NV; ++c)
-      if (c < J && run[c] > 0.0f) pyz[size_t(c) * CC + y * C + z] = run[c];
+    for (int n = 0; n < NVL; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 16 * n + 4 * q + i;
+        if (c < J && run[n][i] > 0.0f) pyz[size_t(c) * CC + y * C + z] = run[n][i];
+      }
   }
 }
 
@@ -475,19 +604,28 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
                                                const int32_t* person_frame, const uint8_t* person_valid,
                                                const int32_t* boxes, const float* fx, const float* fy,
                                                const float* fz, const int32_t* fine, int C, int nP, const FvpGeom* g,
-                                               float* planes, fvp_stream_t s) {
+                                               float* planes, int persons_per_frame, fvp_stream_t s) {
   FVP_REQUIRE(heat_cl && cams && frame_set && person_frame && boxes && fx && fy && fz && planes && nP >= 0);
   (void)fine;
   if (int e = check_geom(g)) return e;
   if (int e = check_cube(C)) return e;
   if (nP == 0) return 0;
+  // persons_per_frame > 0 promises person p belongs to frame p / persons_per_frame (used only to
+  // place the workgroups of one frame on one XCD); 0 = unknown
+  const int ppf = (persons_per_frame > 0 && nP % persons_per_frame == 0) ? persons_per_frame : nP;
+  const int chunks = ceil_div(C * C, 256);
+  const int nvl = ceil_div(g->JP, 16);
   ProfScope ps(FVP_K_PROJECT_TRIPLANE, as_stream(s));
-#define CALL(NV)                                                                                                 \
-  auto k = &k_project_triplane<NV>;                                                                              \
-  hipLaunchKernelGGL(k, dim3(ceil_div(C * C, 256), nP), dim3(256), 0, as_stream(s), heat_cl,                     \
-                     reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, \
-                     C, *g, planes);
-  FVP_NV_SWITCH(g->JP / 4, CALL)
-#undef CALL
+  if (nvl == 1) {
+    auto k = &k_project_triplane<1>;
+    hipLaunchKernelGGL(k, dim3(chunks * nP), dim3(1024), 0, as_stream(s), heat_cl, reinterpret_cast<const Cam*>(cams),
+                       frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP, chunks, ppf, *g, planes);
+  } else if (nvl == 2) {
+    auto k = &k_project_triplane<2>;
+    hipLaunchKernelGGL(k, dim3(chunks * nP), dim3(1024), 0, as_stream(s), heat_cl, reinterpret_cast<const Cam*>(cams),
+                       frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP, chunks, ppf, *g, planes);
+  } else {
+    return FVP_ELIMIT;
+  }
   return launch_status();
 }

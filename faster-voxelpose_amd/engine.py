@@ -318,7 +318,7 @@ class HotPath:
         if fused:
             self._call("fvp_project_individual_triplane", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),
                        _ptr(boxes), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), _ptr(self.fine_dev), Cn, nP, C.byref(g),
-                       _ptr(planes), s)
+                       _ptr(planes), N, s)
         else:
             cubes = self.scratch("person_cubes", (nP, J, Cn, Cn, Cn))
             self._call("fvp_project_individual", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),

@@ -108,12 +108,14 @@ int fvp_triplane_max(const float* cubes, float* planes, int nP, int J, int C, fv
 /* ---- a-14 + a-15 fused (fast path): never materialises the cube ----------------------------
  * Same result as fvp_project_individual followed by fvp_triplane_max, bit for bit
  * (max is order-independent).  planes must be zero-filled by the caller beforehand
- * (hipMemsetAsync); cross-workgroup maxima use integer atomicMax on the non-negative floats. */
+ * (hipMemsetAsync); cross-workgroup maxima use integer atomicMax on the non-negative floats.
+ * persons_per_frame > 0 promises person_frame[p] == p / persons_per_frame (placement hint: the
+ * workgroups of one frame are numbered onto one XCD); pass 0 if unknown. */
 int fvp_project_individual_triplane(const float* heat_cl, const float* cams, const int32_t* frame_set,
                                     const int32_t* person_frame, const uint8_t* person_valid,
                                     const int32_t* boxes, const float* fx, const float* fy, const float* fz,
                                     const int32_t* fine, int C, int nP, const FvpGeom* g, float* planes,
-                                    fvp_stream_t s);
+                                    int persons_per_frame, fvp_stream_t s);
 
 /* ---- a-4/a-5/a-9/a-16: conv stacks ----------------------------------------------------------
  * A stack is a list of FvpConvOp over numbered activation buffers (all NCHW fp32,

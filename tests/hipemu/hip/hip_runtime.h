@@ -141,6 +141,14 @@ static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, 
 #define __builtin_amdgcn_global_load_lds hipemu_glds
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+// DPP quad_perm only (dpp_ctrl < 0x100): lane l reads lane (l & ~3) | sel[l & 3]
+static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
+  (void)old;
+  const int l = hipemu::cur->lane;
+  const int sel = (ctrl >> (2 * (l & 3))) & 3;
+  return hipemu_shfl_from(src, (l & ~3) | sel);
+}
+#define __builtin_amdgcn_update_dpp hipemu_update_dpp
 
 // ---- scalar intrinsics -------------------------------------------------------------------
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
