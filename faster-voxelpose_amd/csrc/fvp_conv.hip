@@ -383,8 +383,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp + co0;
 
   const int tile_px = a.TN * a.TH * a.TW;
-  int poff[PB];
-  unsigned xmask[PB];
+  int poff[PB], txs[PB];                             // txs = tx - padW: tap kx is inside iff 0 <= txs + kx < W
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int q = (wave * PB + pb) * 32 + l31;
@@ -392,10 +391,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
     const int n = qc / (a.TH * W), r = qc - n * (a.TH * W);
     const int ty = r / W, tx = r - ty * W;
     poff[pb] = n * plane_sz + ty * W + tx - padW;
-    unsigned m = 0;
-#pragma unroll
-    for (int kx = 0; kx < KW; ++kx) m |= (tx + kx - padW >= 0 && tx + kx - padW < W) ? (1u << kx) : 0u;
-    xmask[pb] = m;
+    txs[pb] = tx - padW;
   }
 
   f32x16 acc[CB][PB];
@@ -413,20 +409,36 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   const int nwq = a.CC * KK * (CBW / 4);             // 16-byte items of the weight slice
   const int nchunks = (a.cinp + a.CC - 1) / a.CC;
 
+  // The (row, quad) decomposition of this lane's staging items does not depend on the chunk:
+  // do the integer divisions once, keep {source offset within the chunk, channel} per item.
+  constexpr int kMaxIn = 8;                          // host guarantees nin <= kMaxIn * 256
+  int in_off[kMaxIn], in_ci[kMaxIn];
+#pragma unroll
+  for (int j = 0; j < kMaxIn; ++j) {
+    const int it = (wave + 4 * j) * 64 + lane;
+    in_off[j] = -1;
+    in_ci[j] = 0;
+    if (it < nin) {
+      const int row = it / qpr, q = it - row * qpr;
+      const int ci = row / rows_per_ch;
+      const int rem = row - ci * rows_per_ch;
+      const int n = rem / THp, ry = rem - n * THp;
+      const int plane = plane0 + n, y = y0 + ry - padH;
+      in_ci[j] = ci;
+      if (plane < a.planes && y >= 0 && y < a.H) in_off[j] = (n * a.cin + ci) * HW + y * W + 4 * q;
+    }
+  }
+  const float* src_tile = a.src + size_t(plane0) * a.cin * HW;
   auto stage = [&](int k, int buf) {
     float* xs = smem + 4 + buf * buf_sz;
     float* ws = xs + xs_sz;
     const int c0 = k * a.CC;
-    for (int g = wave; g * 64 < nin; g += 4) {
-      const int it = g * 64 + lane;
-      if (it < nin) {
-        const int row = it / qpr, q = it - row * qpr;
-        const int ci = row / rows_per_ch;
-        const int rem = row - ci * rows_per_ch;
-        const int n = rem / THp, ry = rem - n * THp;
-        const int c = c0 + ci, plane = plane0 + n, y = y0 + ry - padH;
-        const bool ok = c < a.cin && plane < a.planes && y >= 0 && y < a.H;
-        const float* src = ok ? a.src + (size_t(plane) * a.cin + c) * HW + size_t(y) * W + 4 * q : a.zeros;
+#pragma unroll
+    for (int j = 0; j < kMaxIn; ++j) {
+      const int g = wave + 4 * j;
+      if (g * 64 + lane < nin) {
+        const bool ok = in_off[j] >= 0 && c0 + in_ci[j] < a.cin;
+        const float* src = ok ? src_tile + size_t(c0) * HW + in_off[j] : a.zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, 0);
       }
@@ -480,7 +492,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
         const int kx = tap % KW;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-          const float b = (KW == 1 || ((xmask[pb] >> kx) & 1u)) ? bv[cur][pb] : 0.0f;
+          const float b = (KW == 1 || unsigned(txs[pb] + kx) < unsigned(W)) ? bv[cur][pb] : 0.0f;
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
             acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][cb], b, acc[cb][pb], 0, 0, 0);
@@ -687,6 +699,8 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   int CC = int((kLdsBudget - 32) / (per_ch * (a.dma ? 2 : 1))) & ~1;
   if (CC > op.cinp) CC = op.cinp;
   if (CC < 2) return FVP_ELIMIT;
+  if (a.dma)                                          // k_conv_dma keeps <= 8 staging items per lane
+    while (CC > 2 && size_t(CC) * a.TN * (a.TH + kh - 1) * (a.TW / 4) > 2048) CC -= 2;
   for (int d = CC; d >= 2 && d * 2 > CC; d -= 2)      // avoid a ragged last chunk when a close divisor exists
     if (op.cinp % d == 0) { CC = d; break; }
   a.CC = CC;

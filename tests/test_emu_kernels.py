@@ -97,3 +97,21 @@ def test_conv_stack_matches_oracle_on_ragged_batch(emu_lib):
     z = torch.from_numpy(np.random.default_rng(2).random((7, J, cfg.CAPTURE_SPEC.VOXELS_PER_AXIS[2]), dtype=np.float32))
     np.testing.assert_allclose(model.pose_net.c2c_net(z).numpy(), O.c2c_net(sd, "pose_net.c2c_net", z).numpy(),
                                rtol=3e-6, atol=3e-6)
+
+
+def test_persistent_conv_walks_tiles_and_skips_masked_planes(emu_lib, monkeypatch):
+    """Force 3 persistent workgroups per conv launch so every workgroup loops over several tiles
+    (cross-tile prefetch, buffer parity) with masked planes in between."""
+    monkeypatch.setenv("FVP_CONV_PERSIST", "3")
+    case = "tiny_g_b2_all"
+    model, cfg, cams, seq, rt, heat, meta = build_model(case, emu_lib)
+    J, Cn = cfg.DATASET.NUM_JOINTS, cfg.INDIVIDUAL_SPEC.VOXELS_PER_AXIS[0]
+    x = torch.from_numpy(np.random.default_rng(5).random((11, J, Cn, Cn), dtype=np.float32))
+    sd = dict(model.state_dict())
+    want = O.p2p_net(sd, "joint_net.conv_net", x)
+    valid = torch.tensor([1, 0, 0, 1, 1, 0, 1, 1, 1, 0, 1], dtype=torch.uint8)
+    got = model.joint_net.conv_net(x, plane_valid=valid, valid_div=1)
+    keep = valid.bool()
+    np.testing.assert_allclose(got[keep].numpy(), want[keep].numpy(), rtol=3e-6, atol=3e-6)
+    got_all = model.joint_net.conv_net(x)
+    np.testing.assert_allclose(got_all.numpy(), want.numpy(), rtol=3e-6, atol=3e-6)
