@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured hipGraph (per-kernel event timing is then unavailable)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,8 +110,16 @@ def main():
     model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
     lib = capi.load()
 
+    graphed = None
+    if args.graph:
+        args.no_prof = True
+        graphed = FV.GraphedForward(model, meta, heat, cams, rt)
+
     def step():
-        fused, planes, centers, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        if graphed is not None:
+            fused = graphed(heat)[0]
+        else:
+            fused, planes, centers, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
         return gather_results(fused, world)
 
     with torch.no_grad():
@@ -180,7 +190,8 @@ def main():
             "config": {"workload": f"{args.config}-shape 5-view synthetic heatmaps, 80x80x20, jln64, "
                                    f"{B} frames/GPU/step, {valid_people:.1f} valid people/frame (MIN_SCORE=-1), "
                                    "seeded random weights", "frames_per_gpu_per_step": B,
-                       "parallelism": f"frame-sharded dp{world}, all_gather of results"},
+                       "parallelism": f"frame-sharded dp{world}, all_gather of results",
+                       "launch": "hipGraph replay" if args.graph else "eager (ctypes launches on the current stream)"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }
         print(json.dumps(line))

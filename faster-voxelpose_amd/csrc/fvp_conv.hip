@@ -32,6 +32,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kStageU = 4;   // independent 16-byte loads in flight per thread while staging
 constexpr int kStageS = 8;   // same for the 4-byte generic path
 
+// Division by a launch-constant: q = umulhi(x, magic), magic = floor(2^32/d) + 1 (exact for
+// 0 <= x < 2^32/d; d == 1 is flagged by magic == 0).  Runtime integer division costs ~40 VALU
+// instructions on gfx950; the index arithmetic of a workgroup used to contain ~90 of them.
+__device__ __forceinline__ int fdiv(int x, unsigned magic) { return magic ? int(__umulhi(unsigned(x), magic)) : x; }
+static unsigned make_magic(int d) { return d <= 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; }
+
 struct ConvArgs {
   const float* src;
   float* dst;
@@ -55,6 +61,7 @@ struct ConvArgs {
   int vec;            // 1: full-width tile with W % 4 == 0 -> 16-byte staging, margin layout
   int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
   int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
+  unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -324,8 +331,8 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&a
         co[j] = co0 + cb * 32 + col;
         const int q = (wave * PB + pb) * 32 + qd * 4;
         const int qc = q < tile_px ? q : 0;
-        const int n = qc / (a.TH * a.TW), r2 = qc - n * (a.TH * a.TW);
-        const int ty = r2 / a.TW, tx = r2 - ty * a.TW;
+        const int n = fdiv(qc, a.m_thw), r2 = qc - n * (a.TH * a.TW);
+        const int ty = fdiv(r2, a.m_w), tx = r2 - ty * a.TW;
         const int plane = plane0 + n, y = y0 + ty;
         ok[j] = q < tile_px && plane < a.planes && y < a.H && co[j] < a.cout;
         off[j] = ok[j] ? unsigned((plane * a.cout + co[j]) * HW + y * a.W + tx) : 0u;
@@ -373,8 +380,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   const int xs_sz = a.CC * CS, ws_sz = a.CC * KK * CBW, buf_sz = xs_sz + ws_sz;   // floats, all % 4 == 0
 
   int tile = blockIdx.x;
-  const int ty_i = tile % a.tiles_y;
-  const int pg = tile / a.tiles_y;
+  const int pg = tile / a.tiles_y;                   // scalar (uniform) division
+  const int ty_i = tile - pg * a.tiles_y;
   const int plane0 = pg * a.TN;
   const int y0 = ty_i * a.TH;
   const int co0 = blockIdx.y * CBW;
@@ -388,8 +395,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   for (int pb = 0; pb < PB; ++pb) {
     const int q = (wave * PB + pb) * 32 + l31;
     const int qc = q < tile_px ? q : 0;
-    const int n = qc / (a.TH * W), r = qc - n * (a.TH * W);
-    const int ty = r / W, tx = r - ty * W;
+    const int n = fdiv(qc, a.m_thw), r = qc - n * (a.TH * W);
+    const int ty = fdiv(r, a.m_w), tx = r - ty * W;
     poff[pb] = n * plane_sz + ty * W + tx - padW;
     txs[pb] = tx - padW;
   }
@@ -419,10 +426,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
     in_off[j] = -1;
     in_ci[j] = 0;
     if (it < nin) {
-      const int row = it / qpr, q = it - row * qpr;
-      const int ci = row / rows_per_ch;
+      const int row = fdiv(it, a.m_qpr), q = it - row * qpr;
+      const int ci = fdiv(row, a.m_rpc);
       const int rem = row - ci * rows_per_ch;
-      const int n = rem / THp, ry = rem - n * THp;
+      const int n = fdiv(rem, a.m_thp), ry = rem - n * THp;
       const int plane = plane0 + n, y = y0 + ry - padH;
       in_ci[j] = ci;
       if (plane < a.planes && y >= 0 && y < a.H) in_off[j] = (n * a.cin + ci) * HW + y * W + 4 * q;
@@ -486,6 +493,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
         constexpr int dummy = 0;
         (void)dummy;
         const int cur = (P + tap) & 1, nxt = cur ^ 1;
+        // wait for this step's operands (issued one step ago) BEFORE issuing the next step's
+        // reads: hipcc only emits lgkmcnt(0), which placed after the new reads would expose
+        // their full LDS latency on every other step
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0), vmcnt/expcnt untouched
+        __builtin_amdgcn_sched_barrier(0);
         if (tap + 1 < KK) fetch(nxt, ci, tap + 1);
         else fetch(nxt, ci + 2, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -686,6 +698,8 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
     a.TH = 1;
     a.TN = 1;
   }
+  a.m_w = make_magic(a.TW);
+  a.m_thw = make_magic(a.TH * a.TW);
   a.tiles_x = ceil_div(op.w, a.TW);
   a.tiles_y = ceil_div(op.h, a.TH);
   const int pgroups = ceil_div(planes, a.TN);
@@ -704,6 +718,9 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   for (int d = CC; d >= 2 && d * 2 > CC; d -= 2)      // avoid a ragged last chunk when a close divisor exists
     if (op.cinp % d == 0) { CC = d; break; }
   a.CC = CC;
+  a.m_qpr = make_magic(a.TW / 4);
+  a.m_rpc = make_magic(a.TN * (a.TH + kh - 1));
+  a.m_thp = make_magic(a.TH + kh - 1);
   const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * twp + 3) & ~size_t(3);
   const size_t lds = a.dma ? std::max<size_t>(16 + 2 * per_ch * CC, 16 + 16384)
                            : (xs_floats + size_t(CC) * kh * kw * 32 * CB) * sizeof(float);

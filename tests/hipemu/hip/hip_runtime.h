@@ -141,6 +141,7 @@ static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, 
 #define __builtin_amdgcn_global_load_lds hipemu_glds
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // DPP quad_perm only (dpp_ctrl < 0x100): lane l reads lane (l & ~3) | sel[l & 3]
 static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
   (void)old;
@@ -156,6 +157,7 @@ static inline float __fmul_rn(float a, float b) { volatile float r = a * b; retu
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return unsigned((uint64_t(a) * b) >> 32); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline long long __double_as_longlong(double d) { long long i; memcpy(&i, &d, 8); return i; }

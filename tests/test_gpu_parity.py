@@ -164,3 +164,24 @@ def test_missing_sequence_and_wrong_device_fail_loudly():
         model(meta={"seq": ["nope"]}, input_heatmaps=heat.to(DEV), cameras=cams, resize_transform=rt)
     with pytest.raises(capi.FvpError):
         model(meta={"seq": [seq]}, input_heatmaps=heat, cameras=cams, resize_transform=rt)   # CPU tensor
+
+
+def test_hipgraph_replay_equals_eager():
+    """The captured hipGraph of the whole path reproduces the eager result bit for bit, also
+    after the static input buffer is refilled with another batch."""
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = S.make_cfg("panoptic", device=DEV, min_score=17.0)
+    cams, seq = S.load_cameras("panoptic")
+    rt = S.resize_transform(cfg).to(DEV)
+    h1 = S.heatmaps_blobs(cfg, cams, seq, 2, people=3, seed=31).to(DEV)
+    h2 = S.heatmaps_blobs(cfg, cams, seq, 2, people=4, seed=32).to(DEV)
+    model, _ = build(cfg)
+    meta = {"seq": [seq] * 2}
+    with torch.no_grad():
+        e1 = [t.clone() for t in model(meta=meta, input_heatmaps=h1, cameras=cams, resize_transform=rt)[:3]]
+        e2 = [t.clone() for t in model(meta=meta, input_heatmaps=h2, cameras=cams, resize_transform=rt)[:3]]
+    g = FV.GraphedForward(model, meta, h1, cams, rt)
+    o1 = [t.clone() for t in g(h1)[:3]]
+    o2 = [t.clone() for t in g(h2)[:3]]
+    for a, b in zip(e1 + e2, o1 + o2):
+        assert torch.equal(a, b)
