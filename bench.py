@@ -60,6 +60,7 @@ def cpu_baseline(cfg_name, frames, seed):
     heat = S.heatmaps_blobs(cfg, cams, seq, 1, people=4, seed=seed)
     orc = O.Oracle(cfg, S.fill_state_dict(O.reference_state_dict_shapes(cfg), seed=7))
     meta = {"seq": [seq]}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))    # 100+ threads oversubscribe these small ops
     orc.forward(heat, meta, cams, rt)                      # warm-up (builds the sampling grid)
     t0 = time.perf_counter()
     for _ in range(frames):
@@ -77,7 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--config", default="panoptic")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -168,7 +169,8 @@ def main():
             proj_gbs = pbytes / (proj["ms_total"] * 1e-3) / 1e9 if proj["ms_total"] > 0 else 0.0
             # dominant kernel by accumulated time decides which roofline is the headline
             if conv["ms_total"] >= proj["ms_total"]:
-                roof = {"kernel": "k_conv (fp32 MFMA implicit GEMM, all conv launches)", "bound": "mfma",
+                roof = {"kernel": "k_conv_dma / k_conv (fp32 MFMA implicit GEMM): every conv launch of CenterNet, "
+                                  "C2CNet and P2PNet, timed per stack run", "bound": "mfma",
                         "achieved": conv_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": conv_tf / MFMA_F32_PEAK_TF, "traffic": None,
                         "avg_launch_us": 1e3 * conv["ms_total"] / max(conv["launches"], 1)}
@@ -176,6 +178,18 @@ def main():
                 roof = {"kernel": "k_project_triplane", "bound": "hbm", "achieved": proj_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": proj_gbs / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": 1e3 * proj["ms_total"] / max(proj["launches"], 1)}
+            # HBM-side traffic of the dominant kernel class from the committed rocprofv3 PMC passes
+            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, mean per conv launch), if present
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.isfile(pmc):
+                try:
+                    with open(pmc) as f:
+                        t = json.load(f)
+                    roof["traffic"] = t.get("conv_mfma_bytes_per_launch" if roof["bound"] == "mfma"
+                                            else "project_triplane_bytes_per_launch")
+                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                except Exception:
+                    pass
             kern["conv_mfma"]["tflops"] = conv_tf
             kern["project_triplane"]["algorithmic_GBps"] = proj_gbs
         cpu = None

@@ -11,8 +11,8 @@ namespace fvp {
 
 struct ProfState {
   std::mutex mu;
-  bool on = false;
-  struct Pair { hipEvent_t a, b; int cls; double flops; };
+  int level = 0;
+  struct Pair { hipEvent_t a, b; int cls; double flops; long launches; };
   std::vector<Pair> open;      // recorded, not yet read back
   std::vector<hipEvent_t> pool;
   double ms[FVP_K_COUNT] = {0};
@@ -33,21 +33,23 @@ static hipEvent_t get_event() {
   return e;
 }
 
+int prof_level() { return g_prof.level; }
+
 void prof_begin(int cls, hipStream_t s) {
-  if (!g_prof.on) return;
+  if (!g_prof.level) return;
   std::lock_guard<std::mutex> lk(g_prof.mu);
   hipEvent_t a = get_event();
   (void)hipEventRecord(a, s);
   g_prof.pending[cls] = a;
 }
 
-void prof_end(int cls, hipStream_t s, double flops) {
-  if (!g_prof.on) return;
+void prof_end(int cls, hipStream_t s, double flops, long launches) {
+  if (!g_prof.level) return;
   std::lock_guard<std::mutex> lk(g_prof.mu);
   if (!g_prof.pending[cls]) return;
   hipEvent_t b = get_event();
   (void)hipEventRecord(b, s);
-  g_prof.open.push_back({g_prof.pending[cls], b, cls, flops});
+  g_prof.open.push_back({g_prof.pending[cls], b, cls, flops, launches});
   g_prof.pending[cls] = nullptr;
 }
 
@@ -57,7 +59,7 @@ static void drain() {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, p.a, p.b);
     g_prof.ms[p.cls] += ms;
-    g_prof.launches[p.cls] += 1;
+    g_prof.launches[p.cls] += p.launches;
     g_prof.flops[p.cls] += p.flops;
     g_prof.pool.push_back(p.a);
     g_prof.pool.push_back(p.b);
@@ -82,7 +84,7 @@ extern "C" const char* fvp_error_string(int code) {
 
 extern "C" int fvp_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.on = on != 0;
+  g_prof.level = on < 0 ? 0 : on;
   return 0;
 }
 

@@ -9,15 +9,25 @@ namespace fvp {
 inline hipStream_t as_stream(fvp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Kernel-class timing used by bench.py's roofline leg (fvp_prof_*).
+// level 0 = off, 1 = coarse (one event pair per conv-stack run, per launch for the other classes),
+// 2 = fine (one pair per conv launch; perturbs a ~100-launch step by >10 %)
+int prof_level();
 void prof_begin(int cls, hipStream_t s);
-void prof_end(int cls, hipStream_t s, double flops);
+void prof_end(int cls, hipStream_t s, double flops, long launches);
 
 struct ProfScope {
   int cls;
   hipStream_t s;
   double flops;
-  ProfScope(int c, hipStream_t st, double f = 0.0) : cls(c), s(st), flops(f) { prof_begin(cls, s); }
-  ~ProfScope() { prof_end(cls, s, flops); }
+  long launches;
+  bool on;
+  ProfScope(int c, hipStream_t st, double f = 0.0, long n = 1, bool enable = true)
+      : cls(c), s(st), flops(f), launches(n), on(enable) {
+    if (on) prof_begin(cls, s);
+  }
+  ~ProfScope() {
+    if (on) prof_end(cls, s, flops, launches);
+  }
 };
 
 inline int launch_status() {

@@ -727,7 +727,7 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   dim3 grid(a.tiles_x * a.tiles_y * pgroups, CBfull / CB, a.ntapT);
   // algorithmic FLOPs (2*MAC on the true channel counts)
   const double taps = tr ? double(a.ntapT) : double(op.kh * op.kw);
-  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * hw * planes);
+  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * hw * planes, 1, prof_level() >= 2);
   return dispatch_conv(kh, kw, CB, PB, a, grid, lds, s);
 }
 
@@ -739,6 +739,18 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
                                   int planes, const uint8_t* plane_valid, int valid_div, fvp_stream_t s) {
   FVP_REQUIRE(ops && params && bufs && nops >= 0 && planes >= 0);
   if (planes == 0) return 0;
+  // coarse profiling: one event pair around the whole stack (the max-pool launches inside are
+  // counted in the time, not in the FLOPs)
+  double flops = 0.0;
+  long nconv = 0;
+  for (int i = 0; i < nops; ++i) {
+    const FvpConvOp& op = ops[i];
+    if (op.kind == FVP_OP_POOL2) continue;
+    const double taps = op.kind == FVP_OP_CONVT2 ? (op.h > 1 ? 4.0 : 2.0) : double(op.kh * op.kw);
+    flops += 2.0 * op.cin * op.cout * taps * op.h * op.w * planes;
+    nconv += 1;
+  }
+  ProfScope stack_scope(FVP_K_CONV, as_stream(s), flops, nconv, prof_level() == 1);
   for (int i = 0; i < nops; ++i) {
     const FvpConvOp& op = ops[i];
     FVP_REQUIRE(op.src >= 0 && op.src < nbufs && op.dst >= 0 && op.dst < nbufs && op.res < nbufs);
@@ -746,7 +758,7 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
     if (op.kind == FVP_OP_POOL2) {
       FVP_REQUIRE(op.w % 2 == 0 && (op.h == 1 || op.h % 2 == 0));
       const long total = long(planes) * op.cin * (op.h > 1 ? op.h / 2 : 1) * (op.w / 2);
-      ProfScope ps(FVP_K_OTHER, as_stream(s));
+      ProfScope ps(FVP_K_OTHER, as_stream(s), 0.0, 1, prof_level() >= 2);
       hipLaunchKernelGGL(k_pool2, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(s),
                          (const float*)bufs[op.src], bufs[op.dst], total, op.h, op.w, plane_valid,
                          valid_div > 0 ? valid_div : 1, op.cin);

@@ -208,9 +208,12 @@ int fvp_fuse_poses(const float* pose2d, const float* pmax, const float* wgt, con
                    float* plane_poses, fvp_stream_t s);
 
 /* ---- measurement hooks (bench.py roofline leg) -----------------------------------------------------
- * When enabled, every launch of kernel class `cls` is bracketed by hipEvents on its own
- * stream; fvp_prof_read synchronises those events and returns accumulated milliseconds and
- * launch count since the last reset. */
+ * fvp_prof_enable(1): kernel classes are bracketed by hipEvents on the stream they are launched
+ * on -- per launch for the projection / soft-argmax / small kernels, one pair per
+ * fvp_conv_stack_run for the conv class (launches = convs in the stack), so that a ~100-launch
+ * step is not perturbed.  fvp_prof_enable(2): additionally one pair per conv launch (diagnostics).
+ * fvp_prof_read synchronises the events and returns accumulated milliseconds, launch count and
+ * algorithmic FLOPs since the last reset. */
 enum { FVP_K_PROJECT_WHOLE = 0, FVP_K_PROJECT_TRIPLANE = 1, FVP_K_CONV = 2, FVP_K_SOFTARGMAX = 3,
        FVP_K_OTHER = 4, FVP_K_COUNT = 5 };
 int fvp_prof_enable(int on);
