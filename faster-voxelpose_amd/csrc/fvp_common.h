@@ -4,6 +4,12 @@
 
 #include "../../include/fvp.h"
 
+// Make a wave-uniform integer opaque to the optimiser at this point (stops loop-invariant code
+// motion from hoisting dozens of derived LDS addresses out of a hot loop into live registers).
+#ifndef FVP_OPAQUE
+#define FVP_OPAQUE(x) asm volatile("" : "+s"(x))
+#endif
+
 namespace fvp {
 
 inline hipStream_t as_stream(fvp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

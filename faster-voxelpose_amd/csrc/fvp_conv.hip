@@ -362,9 +362,11 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&a
 // Pipelined conv for full-width tiles with W % 4 == 0 (every 2-D layer of the three nets):
 // chunk k+1 is copied HBM/L2 -> LDS by the LDS-DMA (global_load_lds, 16 B per lane, no VGPRs)
 // while the matrix cores work on chunk k; two LDS buffers, one barrier per chunk.
-//   Xs[buf][CC][TN][TH+KH-1][W]   dense rows (the DMA writes base + lane*16); the horizontal halo
-//                                  is a per-lane bit mask applied to the B operand, the vertical
-//                                  halo / channel padding / missing planes read a zero page
+//   Xs[buf][CC][TN][TH+KH-1][4 + W]  every row slot starts with a 16-byte zero margin (its DMA
+//                                  lanes read the zero page), so the slots stay dense for the DMA
+//                                  (base + lane*16) and the left / right halo taps read zeros
+//                                  without any per-operand masking; rows above / below the image,
+//                                  channel padding and missing planes also read the zero page
 //   Ws[buf][CC][KH*KW][32*CB]
 template <int KH, int KW, int CB, int PB>
 __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
@@ -374,10 +376,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   constexpr int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int THp = a.TH + KH - 1, W = a.W;
-  const int plane_sz = THp * W;
+  const int THp = a.TH + KH - 1, W = a.W, WP = W + 4;
+  const int plane_sz = THp * WP;
   const int CS = a.TN * plane_sz;
-  const int xs_sz = a.CC * CS, ws_sz = a.CC * KK * CBW, buf_sz = xs_sz + ws_sz;   // floats, all % 4 == 0
+  const int xs_sz = a.CC * CS + 4, ws_sz = a.CC * KK * CBW, buf_sz = xs_sz + ws_sz;   // floats, all % 4 == 0
 
   int tile = blockIdx.x;
   const int pg = tile / a.tiles_y;                   // scalar (uniform) division
@@ -390,15 +392,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp + co0;
 
   const int tile_px = a.TN * a.TH * a.TW;
-  int poff[PB], txs[PB];                             // txs = tx - padW: tap kx is inside iff 0 <= txs + kx < W
+  int poff[PB];
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int q = (wave * PB + pb) * 32 + l31;
     const int qc = q < tile_px ? q : 0;
     const int n = fdiv(qc, a.m_thw), r = qc - n * (a.TH * W);
     const int ty = fdiv(r, a.m_w), tx = r - ty * W;
-    poff[pb] = n * plane_sz + ty * W + tx - padW;
-    txs[pb] = tx - padW;
+    poff[pb] = n * plane_sz + ty * WP + 4 + tx - padW;
   }
 
   f32x16 acc[CB][PB];
@@ -410,9 +411,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.0f;
 
   const int HW = a.H * W;
-  const int qpr = W >> 2;
+  const int qpr = (W >> 2) + 1;                      // quads per row slot, quad 0 = zero margin
   const int rows_per_ch = a.TN * THp;
-  const int nin = a.CC * rows_per_ch * qpr;          // 16-byte items of the input tile
+  const int nin = a.CC * rows_per_ch * qpr + 1;      // 16-byte items of the input tile (+ tail zero quad)
   const int nwq = a.CC * KK * (CBW / 4);             // 16-byte items of the weight slice
   const int nchunks = (a.cinp + a.CC - 1) / a.CC;
 
@@ -432,7 +433,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
       const int n = fdiv(rem, a.m_thp), ry = rem - n * THp;
       const int plane = plane0 + n, y = y0 + ry - padH;
       in_ci[j] = ci;
-      if (plane < a.planes && y >= 0 && y < a.H) in_off[j] = (n * a.cin + ci) * HW + y * W + 4 * q;
+      if (q > 0 && ci < a.CC && plane < a.planes && y >= 0 && y < a.H)
+        in_off[j] = (n * a.cin + ci) * HW + y * W + 4 * (q - 1);
     }
   }
   const float* src_tile = a.src + size_t(plane0) * a.cin * HW;
@@ -476,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
     // full LDS latency).  Two register sets; KK is odd for every kernel shape, so consecutive
     // channel pairs alternate the starting set (template parameter P).
     float av[2][CB], bv[2][PB];
-    auto fetch = [&](int set, int ci, int tap) {
+    auto fetch = [&](int set, int ci, int tap, int wp) {
       const int cic = ci < a.CC ? ci : a.CC - 2;              // last prefetch of a chunk: harmless re-read
       const float* xs = Xs + (cic + half) * CS;
       const float* ws = Ws + (cic + half) * KK * CBW + l31;
@@ -484,27 +486,27 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) av[set][cb] = ws[tap * CBW + cb * 32];
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) bv[set][pb] = xs[poff[pb] + ky * W + kx];
+      for (int pb = 0; pb < PB; ++pb) bv[set][pb] = xs[poff[pb] + ky * wp + kx];
     };
     auto block = [&](auto parity, int ci) {
       constexpr int P = decltype(parity)::value;
+      int wp = WP;
+      FVP_OPAQUE(wp);                                  // row addresses are recomputed per channel pair, not kept live
 #pragma unroll
       for (int tap = 0; tap < KK; ++tap) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int cur = (P + tap) & 1, nxt = cur ^ 1;
         // wait for this step's operands (issued one step ago) BEFORE issuing the next step's
         // reads: hipcc only emits lgkmcnt(0), which placed after the new reads would expose
         // their full LDS latency on every other step
         __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0), vmcnt/expcnt untouched
         __builtin_amdgcn_sched_barrier(0);
-        if (tap + 1 < KK) fetch(nxt, ci, tap + 1);
-        else fetch(nxt, ci + 2, 0);
+        if (tap + 1 < KK) fetch(nxt, ci, tap + 1, wp);
+        else fetch(nxt, ci + 2, 0, wp);
         __builtin_amdgcn_sched_barrier(0);
         const int kx = tap % KW;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-          const float b = (KW == 1 || unsigned(txs[pb] + kx) < unsigned(W)) ? bv[cur][pb] : 0.0f;
+          const float b = bv[cur][pb];
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
             acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][cb], b, acc[cb][pb], 0, 0, 0);
@@ -513,7 +515,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
       }
     };
     if (!(a.ablate & 4)) {
-      fetch(0, 0, 0);
+      fetch(0, 0, 0, WP);
       for (int ci = 0; ci < a.CC; ci += 4) {
         block(std::integral_constant<int, 0>{}, ci);
         if (ci + 2 < a.CC) block(std::integral_constant<int, 1>{}, ci + 2);
@@ -707,22 +709,22 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   a.vec = (a.TW == op.w && op.w % 4 == 0) ? 1 : 0;
   a.dma = (a.vec && !kNoDma) ? 1 : 0;
   a.zeros = params;
-  const int twp = a.dma ? a.TW : (a.vec ? a.TW + 8 : a.TW + kw - 1);
+  const int twp = a.dma ? a.TW + 4 : (a.vec ? a.TW + 8 : a.TW + kw - 1);
   const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * twp + size_t(kh) * kw * 32 * CB) * sizeof(float);
   // the pipelined kernel keeps two chunks in LDS
-  int CC = int((kLdsBudget - 32) / (per_ch * (a.dma ? 2 : 1))) & ~1;
+  int CC = int((kLdsBudget - 64) / (per_ch * (a.dma ? 2 : 1))) & ~1;
   if (CC > op.cinp) CC = op.cinp;
   if (CC < 2) return FVP_ELIMIT;
   if (a.dma)                                          // k_conv_dma keeps <= 8 staging items per lane
-    while (CC > 2 && size_t(CC) * a.TN * (a.TH + kh - 1) * (a.TW / 4) > 2048) CC -= 2;
+    while (CC > 2 && size_t(CC) * a.TN * (a.TH + kh - 1) * (a.TW / 4 + 1) + 1 > 2048) CC -= 2;
   for (int d = CC; d >= 2 && d * 2 > CC; d -= 2)      // avoid a ragged last chunk when a close divisor exists
     if (op.cinp % d == 0) { CC = d; break; }
   a.CC = CC;
-  a.m_qpr = make_magic(a.TW / 4);
+  a.m_qpr = make_magic(a.dma ? a.TW / 4 + 1 : a.TW / 4);
   a.m_rpc = make_magic(a.TN * (a.TH + kh - 1));
   a.m_thp = make_magic(a.TH + kh - 1);
   const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * twp + 3) & ~size_t(3);
-  const size_t lds = a.dma ? std::max<size_t>(16 + 2 * per_ch * CC, 16 + 16384)
+  const size_t lds = a.dma ? std::max<size_t>(16 + 2 * (per_ch * CC + 16), 16 + 16384)
                            : (xs_floats + size_t(CC) * kh * kw * 32 * CB) * sizeof(float);
   dim3 grid(a.tiles_x * a.tiles_y * pgroups, CBfull / CB, a.ntapT);
   // algorithmic FLOPs (2*MAC on the true channel counts)

@@ -25,6 +25,7 @@
 #include <functional>
 
 #define HIPEMU 1
+#define FVP_OPAQUE(x) ((void)0)
 #define __global__
 #define __device__
 #define __host__

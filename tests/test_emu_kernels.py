@@ -99,10 +99,8 @@ def test_conv_stack_matches_oracle_on_ragged_batch(emu_lib):
                                rtol=3e-6, atol=3e-6)
 
 
-def test_persistent_conv_walks_tiles_and_skips_masked_planes(emu_lib, monkeypatch):
-    """Force 3 persistent workgroups per conv launch so every workgroup loops over several tiles
-    (cross-tile prefetch, buffer parity) with masked planes in between."""
-    monkeypatch.setenv("FVP_CONV_PERSIST", "3")
+def test_conv_ragged_masked_batch_and_centernet(emu_lib):
+    """Ragged plane count with masked planes through P2PNet, and CenterNet on its own."""
     case = "tiny_g_b2_all"
     model, cfg, cams, seq, rt, heat, meta = build_model(case, emu_lib)
     J, Cn = cfg.DATASET.NUM_JOINTS, cfg.INDIVIDUAL_SPEC.VOXELS_PER_AXIS[0]
@@ -115,3 +113,10 @@ def test_persistent_conv_walks_tiles_and_skips_masked_planes(emu_lib, monkeypatc
     np.testing.assert_allclose(got[keep].numpy(), want[keep].numpy(), rtol=3e-6, atol=3e-6)
     got_all = model.joint_net.conv_net(x)
     np.testing.assert_allclose(got_all.numpy(), want.numpy(), rtol=3e-6, atol=3e-6)
+    # CenterNet geometry (16x16 map of the tiny config) through the same path
+    X, Y, Z = cfg.CAPTURE_SPEC.VOXELS_PER_AXIS
+    cubes = torch.from_numpy(np.random.default_rng(6).random((3, J, X, Y, Z), dtype=np.float32))
+    hm_w, sz_w = O.center_net(sd, "pose_net.center_net", cubes)
+    hm, sz = model.pose_net.center_net(cubes)
+    np.testing.assert_allclose(hm.numpy(), hm_w.numpy(), rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(sz.numpy(), sz_w.numpy(), rtol=2e-5, atol=5e-5)
