@@ -51,6 +51,7 @@ SIGNATURES = {
     "fvp_triplane_max": [_P, _P, _I, _I, _I, _P],
     "fvp_project_individual_triplane": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _G, _P, _I, _P],
     "fvp_conv_stack_run": [C.POINTER(FvpConvOp), _I, _P, C.POINTER(_P), _I, _I, _P, _I, _P],
+    "fvp_conv_stack_run_fused_1d": [C.POINTER(FvpConvOp), _I, _P, _P, _P, _I, _P],
     "fvp_pack_conv": [_P, _P, _P, _P, _P, _P, _F, _I, C.POINTER(FvpConvOp), _P, _P],
     "fvp_nms_topk": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
     "fvp_gather_proposals": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -12,6 +12,12 @@
 
 namespace fvp {
 
+// Conv epilogue affine (bias, then eval-BatchNorm scale/shift) with a pinned operation order so
+// that every kernel variant produces the same bits: one rounding for acc + bias, one fma.
+__device__ __forceinline__ float bn_affine(float acc, float bias, float scale, float shift) {
+  return __fmaf_rn(acc + bias, scale, shift);
+}
+
 inline hipStream_t as_stream(fvp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Kernel-class timing used by bench.py's roofline leg (fvp_prof_*).

@@ -104,8 +104,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // < coutp: epi vectors are padded
-        float v = acc[cb][pb][r] + bias[co];
-        v = v * scale[co] + shift[co];
+        float v = bn_affine(acc[cb][pb][r], bias[co], scale[co], shift[co]);
         if (HAS_RES && !res_after) v += rv[r];
         if (relu) v = fmaxf(v, 0.0f);
         if (HAS_RES && res_after) v += rv[r];
@@ -346,7 +345,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&a
                              HAS_RES ? rv[j].w : 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x = (o[e] + b) * sc_ + sh;
+          float x = bn_affine(o[e], b, sc_, sh);
           if (HAS_RES && !res_after) x += rr[e];
           if (relu) x = fmaxf(x, 0.0f);
           if (HAS_RES && res_after) x += rr[e];

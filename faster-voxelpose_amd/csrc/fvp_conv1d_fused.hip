@@ -1,0 +1,331 @@
+// Whole 1-D conv stack (C2CNet, lib/models/cnns_1d.py:112-132) in ONE kernel, one workgroup per
+// proposal column.  The generic interpreter needs 25 dependent launches of 8-40 us for a net
+// that is 4.9 MFLOP per proposal; here all activations (<= 128 channels x <= 24 positions) stay in
+// LDS, weights stream from L2 straight into the MFMA A operand through a register prefetch
+// ring, and layers are separated by one workgroup barrier instead of a kernel boundary.
+//
+// LDS: every channel of an activation buffer is a row slot of `slotw` floats = 4 zero columns |
+// L data | zero tail (slotw >= L + 8, <= 32); the MFMA pixel lane j is slot column j, so a tap
+// reads column j + k - pad and the halo is the zero margin.  Epilogues write whole slots (zeros
+// outside the data columns), which lets buffers share LDS space by live range.
+// Wave w owns cout block w (32 couts); accumulation order per output is the k-ordered chain
+// (channel pairs, then taps) of the generic kernel, so both paths give identical results.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "fvp_common.h"
+
+namespace fvp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMaxOps = 32, kMaxBufs = 40, kMaxChunks = 112;
+constexpr int kWFloats = 12288;                       // floats per weight buffer (LDS-DMA ring)
+constexpr int kNB = 2;                               // ring depth: chunk c+1 streams in while chunk c computes
+
+// One pipeline step of the fused stack: `nrows` weight rows (row = (ci, tap), coutp floats each) of
+// op `op` starting at row0, or a weight-less step (pool / slot clearing) when nrows == 0.
+struct Chunk {
+  short op, tap;             // tap: transposed-conv tap (0 / 1), else 0
+  short row0, nrows;
+  short first, last;         // first / last chunk of this (op, tap)
+};
+
+struct Fused1dArgs {
+  FvpConvOp ops[kMaxOps];
+  Chunk chunks[kMaxChunks];
+  int buf_off[kMaxBufs];     // LDS float offset of each activation buffer
+  int buf_w[kMaxBufs];       // slot width (floats) of each buffer
+  int nops, nchunks, planes, cin, L, lds_floats;
+  const float* params;
+  const float* in;           // [planes][cin][L]
+  float* out;                // [planes][cout_last][L_last]
+};
+
+// s_waitcnt vmcnt(n) with lgkmcnt / expcnt left alone (simm16: vmcnt[3:0] | expcnt 7<<4 | lgkmcnt 15<<8)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+  }
+}
+
+template <int KW>
+__device__ __forceinline__ void conv_chunk(const Fused1dArgs& a, const FvpConvOp& op, const Chunk& ch,
+                                           const float* lds, const float* wbuf, f32x16& acc, int lane, int cb) {
+  const int half = lane >> 5, l31 = lane & 31;
+  constexpr int pad = (KW - 1) / 2;
+  const int sw = a.buf_w[op.src];
+  const float* in = lds + a.buf_off[op.src] + l31 - pad + (2 * (ch.row0 / (2 * KW)) + half) * sw;
+  const float* ws = wbuf + cb * 32 + l31 + half * KW * op.coutp;
+  const int np = ch.nrows / (2 * KW);
+  for (int p = 0; p < np; ++p) {
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+      const float av = ws[(2 * p * KW + t) * op.coutp];
+      const float bv = in[2 * p * sw + t];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_conv1d_fused(Fused1dArgs a) {
+  HIP_DYNAMIC_SHARED(float, lds)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int plane = blockIdx.x;
+  float* const wbufs = lds + a.lds_floats;           // two weight buffers behind the activation arena
+
+  // LDS-DMA of chunk c's weight rows into ring slot c % kNB; returns this wave's instruction count
+  auto stage = [&](int c) -> int {
+    if (c >= a.nchunks) return 0;
+    const Chunk& ch = a.chunks[c];
+    if (ch.nrows == 0) return 0;
+    const FvpConvOp& op = a.ops[ch.op];
+    const float* src = a.params + op.w_off + size_t(ch.tap) * op.cinp * op.coutp + size_t(ch.row0) * op.coutp;
+    float* dst = wbufs + (c % kNB) * kWFloats;
+    const int nq = ch.nrows * op.coutp / 4;
+    int n = 0;
+    for (int g = wave; g * 64 < nq; g += 4) {
+      const int it = g * 64 + lane;
+      ++n;
+      if (it < nq)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + it * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + g * 256), 16, 0, 0);
+    }
+    return n;
+  };
+
+  // in flight: chunks c+1 .. c+kNB-1 while chunk c computes; ninfl[k] = this wave's DMA count of c+1+k
+  int ninfl[kNB - 1];
+  stage(0);
+#pragma unroll
+  for (int k = 0; k < kNB - 1; ++k) ninfl[k] = stage(1 + k);
+  // the arena starts zeroed: channel-padding rows and out-of-slot halo reads must hit finite values
+  for (int i = t; i < a.lds_floats; i += 256) lds[i] = 0.0f;
+  __syncthreads();
+  {                                                  // input -> buffer 0 (whole slots: zero margins)
+    const int sw = a.buf_w[0];
+    float* b0 = lds + a.buf_off[0];
+    const float* src = a.in + size_t(plane) * a.cin * a.L;
+    for (int i = t; i < a.cin * sw; i += 256) {
+      const int c = i / sw, j = i - c * sw;
+      b0[i] = (j >= 4 && j < 4 + a.L) ? src[c * a.L + (j - 4)] : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int c = 0; c < a.nchunks; ++c) {
+    // ring slot (c + kNB - 1) % kNB was last read during chunk c - 1, which every wave has left
+    if (c > 0) {
+#pragma unroll
+      for (int k = 0; k < kNB - 2; ++k) ninfl[k] = ninfl[k + 1];
+      ninfl[kNB - 2] = stage(c + kNB - 1);
+    }
+    // end-of-chunk rendezvous: LDS writes done, chunk c+1 landed, younger DMAs may stay in flight
+    auto rendezvous = [&]() {
+      int keep = 0;
+#pragma unroll
+      for (int k = 1; k < kNB - 1; ++k) keep += ninfl[k];
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0)
+      wait_vmcnt(keep);
+      __builtin_amdgcn_s_barrier();
+    };
+    const Chunk& ch = a.chunks[c];
+    const FvpConvOp& op = a.ops[ch.op];
+    const int Lin = op.w;
+    if (ch.nrows == 0) {
+      if (op.kind == FVP_OP_POOL2) {
+        const int sw = a.buf_w[op.src], dw = a.buf_w[op.dst], Lo = Lin / 2;
+        const float* s = lds + a.buf_off[op.src];
+        float* d = lds + a.buf_off[op.dst];
+        for (int i = t; i < op.cin * dw; i += 256) {
+          const int cc = i / dw, j = i - cc * dw;
+          float v = 0.0f;
+          if (j >= 4 && j < 4 + Lo) v = fmaxf(s[cc * sw + 4 + 2 * (j - 4)], s[cc * sw + 4 + 2 * (j - 4) + 1]);
+          d[i] = v;
+        }
+      } else {                                       // transposed conv: clear the slots before the scatter
+        float* d = lds + a.buf_off[op.dst];
+        const int n = op.cout * a.buf_w[op.dst];
+        for (int i = t; i < n; i += 256) d[i] = 0.0f;
+      }
+      rendezvous();
+      continue;
+    }
+    const bool tr = op.kind == FVP_OP_CONVT2;
+    const int ncb = op.coutp / 32;
+    if (wave < ncb) {
+      if (ch.first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      }
+      const float* wbuf = wbufs + (c % kNB) * kWFloats;
+      if (tr || op.kw == 1) conv_chunk<1>(a, op, ch, lds, wbuf, acc, lane, wave);
+      else if (op.kw == 3) conv_chunk<3>(a, op, ch, lds, wbuf, acc, lane, wave);
+      else conv_chunk<7>(a, op, ch, lds, wbuf, acc, lane, wave);
+      if (ch.last) {
+        // ---- epilogue: slot column j = l31; data columns [4, 4 + Lin)
+        const int Lo = tr ? 2 * Lin : Lin;
+        const int dw = a.buf_w[op.dst];
+        const bool final_op = ch.op == a.nops - 1;
+        float* dst = lds + a.buf_off[op.dst];
+        const float* bias = a.params + op.e_off;
+        const float* scale = bias + op.coutp;
+        const float* shift = bias + 2 * op.coutp;
+        const bool relu = op.flags & FVP_EPI_RELU, has_res = op.flags & FVP_EPI_RES;
+        const bool res_after = op.flags & FVP_EPI_RES_AFTER_RELU;
+        const float* res = has_res ? lds + a.buf_off[op.res] : nullptr;
+        const int rw = has_res ? a.buf_w[op.res] : 0;
+        const int x = l31 - 4;
+        const bool data = x >= 0 && x < Lin;
+        const int oc = tr ? 4 + 2 * x + ch.tap : l31;  // output slot column
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (co < op.cout) {
+            float v = bn_affine(acc[r], bias[co], scale[co], shift[co]);
+            if (data) {
+              if (has_res && !res_after) v += res[co * rw + oc];
+              if (relu) v = fmaxf(v, 0.0f);
+              if (has_res && res_after) v += res[co * rw + oc];
+            } else {
+              v = 0.0f;
+            }
+            if (final_op) {
+              if (data) a.out[(size_t(plane) * op.cout + co) * Lo + (tr ? 2 * x + ch.tap : x)] = v;
+            } else if (tr) {
+              if (data) dst[co * dw + oc] = v;
+            } else if (l31 < dw) {
+              dst[co * dw + l31] = v;
+            }
+          }
+        }
+      }
+    }
+    rendezvous();                                    // chunk consumed, next weights landed, outputs visible
+  }
+}
+
+}  // namespace fvp
+
+using namespace fvp;
+
+extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const float* params, const float* in,
+                                           float* out, int planes, fvp_stream_t s) {
+  FVP_REQUIRE(ops && params && in && out && nops > 0 && planes >= 0);
+  FVP_LIMIT(nops <= kMaxOps);
+  if (planes == 0) return 0;
+  Fused1dArgs a;
+  std::memset(&a, 0, sizeof(a));
+  // ---- validate the stack and find buffer geometry (channels, length) + live ranges
+  int nbufs = 0, chan[kMaxBufs], len[kMaxBufs], first[kMaxBufs], lastuse[kMaxBufs];
+  for (int i = 0; i < kMaxBufs; ++i) { chan[i] = 0; len[i] = 0; first[i] = -1; lastuse[i] = -1; }
+  double flops = 0.0;
+  for (int i = 0; i < nops; ++i) {
+    const FvpConvOp& op = ops[i];
+    FVP_REQUIRE(op.h == 1 && op.src >= 0 && op.dst >= 0);
+    FVP_LIMIT(op.src < kMaxBufs && op.dst < kMaxBufs && op.res < kMaxBufs && op.w <= 24 && op.coutp <= 128);
+    const int Lo = op.kind == FVP_OP_CONVT2 ? 2 * op.w : (op.kind == FVP_OP_POOL2 ? op.w / 2 : op.w);
+    FVP_LIMIT(Lo <= 24);
+    if (op.kind == FVP_OP_CONV) FVP_LIMIT(op.kh == 1 && (op.kw == 1 || op.kw == 3 || op.kw == 7));
+    chan[op.src] = op.cin;
+    len[op.src] = op.w;
+    chan[op.dst] = op.cout;
+    len[op.dst] = Lo;
+    if (first[op.src] < 0) first[op.src] = -1;       // only the stack input is never defined
+    if (first[op.dst] < 0) first[op.dst] = i;
+    lastuse[op.src] = i;
+    if (op.res >= 0) lastuse[op.res] = i;
+    if (op.dst + 1 > nbufs) nbufs = op.dst + 1;
+    if (op.src + 1 > nbufs) nbufs = op.src + 1;
+    if (op.kind != FVP_OP_POOL2)
+      flops += 2.0 * op.cin * op.cout * (op.kind == FVP_OP_CONVT2 ? 2.0 : double(op.kw)) * op.w * planes;
+    a.ops[i] = op;
+  }
+  // ---- LDS placement: first-fit over live ranges [def, last use]
+  int off[kMaxBufs], size[kMaxBufs];
+  int total = 0;
+  for (int b = 0; b < nbufs; ++b) {
+    const int sw = ((len[b] + 8 + 3) / 4) * 4;        // 4 margin | L | >= 4 tail, multiple of 4
+    FVP_LIMIT(sw <= 32);
+    a.buf_w[b] = sw;
+    size[b] = chan[b] * sw;
+  }
+  for (int b = 0; b < nbufs; ++b) {
+    if (chan[b] == 0) { off[b] = 0; continue; }
+    int pos = 0;
+    bool moved = true;
+    while (moved) {
+      moved = false;
+      for (int o = 0; o < b; ++o) {
+        if (chan[o] == 0) continue;
+        const bool live_overlap = !(lastuse[o] < first[b] || lastuse[b] < first[o]);
+        if (live_overlap && pos < off[o] + size[o] && off[o] < pos + size[b]) {
+          pos = off[o] + size[o];
+          moved = true;
+        }
+      }
+    }
+    off[b] = pos;
+    if (pos + size[b] > total) total = pos + size[b];
+  }
+  for (int b = 0; b < nbufs; ++b) a.buf_off[b] = off[b];
+  // ---- chunk list: weight rows in LDS-DMA pieces of <= kWFloats, whole channel pairs per piece
+  int nch = 0;
+  auto push = [&](int op, int tap, int row0, int nrows, int first, int last) {
+    if (nch < kMaxChunks) {
+      Chunk& c = a.chunks[nch];
+      c.op = short(op); c.tap = short(tap); c.row0 = short(row0); c.nrows = short(nrows);
+      c.first = short(first); c.last = short(last);
+    }
+    ++nch;
+  };
+  for (int i = 0; i < nops; ++i) {
+    const FvpConvOp& op = ops[i];
+    if (op.kind == FVP_OP_POOL2) { push(i, 0, 0, 0, 1, 1); continue; }
+    const bool tr = op.kind == FVP_OP_CONVT2;
+    const int kk = tr ? 1 : op.kw;
+    const int rows = op.cinp * kk;
+    int per = (kWFloats / op.coutp) / (2 * kk) * (2 * kk);
+    FVP_LIMIT(per >= 2 * kk);
+    if (tr) push(i, 0, 0, 0, 1, 1);                    // slot clearing before the strided scatter
+    for (int tap = 0; tap < (tr ? 2 : 1); ++tap)
+      for (int r0 = 0; r0 < rows; r0 += per)
+        push(i, tap, r0, rows - r0 < per ? rows - r0 : per, r0 == 0, r0 + per >= rows);
+  }
+  FVP_LIMIT(nch <= kMaxChunks);
+  a.nchunks = nch;
+  a.nops = nops;
+  a.planes = planes;
+  a.cin = ops[0].cin;
+  a.L = ops[0].w;
+  total = (total + 64 + 3) & ~3;                     // slack for channel-padding rows; keeps the weight buffers 16-B aligned
+  a.lds_floats = total;
+  a.params = params;
+  a.in = in;
+  a.out = out;
+  const size_t lds = size_t(total + kNB * kWFloats) * sizeof(float);
+  FVP_LIMIT(lds <= 160 * 1024);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1d_fused),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
+    return FVP_ELIMIT;
+  ProfScope ps(FVP_K_CONV, as_stream(s), flops, nops, prof_level() >= 1);
+  hipLaunchKernelGGL(k_conv1d_fused, dim3(planes), dim3(256), lds, as_stream(s), a);
+  return launch_status();
+}

@@ -93,6 +93,7 @@ class HotPath:
         self._heat_cl = None
         self._person_frame = {}
         self._scratch = {}
+        self.fused_c2c = True        # C2CNet as one kernel per batch (False: generic conv interpreter)
 
     # ---------------------------------------------------------------------------------------------
     def stream(self):
@@ -228,6 +229,15 @@ class HotPath:
                    planes, _ptr(plane_valid), valid_div, self.stream())
         return {k: bufs[i] for k, i in spec.outputs.items()}
 
+    def run_stack_fused_1d(self, name, x, planes):
+        """Whole 1-D stack in one kernel (fvp_conv_stack_run_fused_1d); x = [planes, cin, 1, W]."""
+        spec = self.specs[name]
+        c, h, w = spec.bufs[spec.outputs["out"]]
+        out = self.scratch(f"{name}.fused_out", (planes, c, h, w))
+        self._call("fvp_conv_stack_run_fused_1d", spec.op_array, len(spec.ops), _ptr(self.params[name]), _ptr(x),
+                   _ptr(out), planes, self.stream())
+        return {"out": out}
+
     # ---- operator groups ------------------------------------------------------------------------------------
     def project_whole(self, heatmaps, meta, cameras, resize_transform, want_cubes=True, want_zmax=False):
         B, V = heatmaps.shape[:2]
@@ -270,7 +280,10 @@ class HotPath:
         feat1d = self.scratch("feat1d", (B * N, J, 1, Z))
         self._call("fvp_gather_proposals", _ptr(bbox_map), _ptr(cubes), _ptr(flat), B, J, X, Y, Z, N, _ptr(bbox_flat),
                    _ptr(match_bbox), _ptr(feat1d), s)
-        hm1d = self.run_stack("c2c_net", feat1d, B * N)["out"].view(B, N, Z).clone()
+        if self.fused_c2c and Z <= 24:
+            hm1d = self.run_stack_fused_1d("c2c_net", feat1d, B * N)["out"].view(B, N, Z).clone()
+        else:
+            hm1d = self.run_stack("c2c_net", feat1d, B * N)["out"].view(B, N, Z).clone()
         centers = torch.empty((B, N, 7), device=dev)
         topk_index = self.scratch("topk_index", (B, N, 3), torch.int64)
         self._call("fvp_proposals", _ptr(hm1d), _ptr(conf2d), _ptr(idx2d), _ptr(match_bbox), _ptr(self.prop_sb),

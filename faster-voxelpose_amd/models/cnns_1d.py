@@ -19,5 +19,9 @@ class C2CNet(PackedNet):
         self.ensure_packed()
         e._check_tensor(x, "columns")
         n, J, Z = x.shape
-        out = e.run_stack("c2c_net", x.contiguous().view(n, J, 1, Z), n)["out"].view(n, 1, Z)
+        xin = x.contiguous().view(n, J, 1, Z)
+        if e.fused_c2c and Z <= 24:
+            out = e.run_stack_fused_1d("c2c_net", xin, n)["out"].view(n, 1, Z)
+        else:
+            out = e.run_stack("c2c_net", xin, n)["out"].view(n, 1, Z)
         return out.clone() if _clone else out

@@ -151,6 +151,13 @@ typedef struct FvpConvOp {
 int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* params, float* const* bufs, int nbufs,
                        int planes, const uint8_t* plane_valid, int valid_div, fvp_stream_t s);
 
+/* The same interpreter for a 1-D stack (H = 1, W <= 24, cout <= 128: C2CNet) fused into ONE
+ * kernel, one workgroup per plane, activations resident in LDS.  in = [planes][cin][W] (buffer
+ * ops[0].src), out = [planes][cout][W'] of the last op.  Results are identical to
+ * fvp_conv_stack_run (same accumulation order). */
+int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const float* params, const float* in,
+                                float* out, int planes, fvp_stream_t s);
+
 /* Pack one conv's parameters from the reference's state_dict tensors (device copies):
  * weight [cout][cin][kh][kw] (or [cin][cout][kh][kw] when transposed) -> [tap][cinp][coutp];
  * bias / BN vectors -> bias|scale|shift with scale = gamma/sqrt(var+eps), shift = beta - mean*scale

@@ -143,6 +143,7 @@ static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, 
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
 // DPP quad_perm only (dpp_ctrl < 0x100): lane l reads lane (l & ~3) | sel[l & 3]
 static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
   (void)old;

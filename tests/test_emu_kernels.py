@@ -120,3 +120,19 @@ def test_conv_ragged_masked_batch_and_centernet(emu_lib):
     hm, sz = model.pose_net.center_net(cubes)
     np.testing.assert_allclose(hm.numpy(), hm_w.numpy(), rtol=2e-5, atol=5e-5)
     np.testing.assert_allclose(sz.numpy(), sz_w.numpy(), rtol=2e-5, atol=5e-5)
+
+
+def test_fused_c2c_equals_generic_interpreter(emu_lib):
+    """fvp_conv_stack_run_fused_1d (whole C2CNet in one kernel) == the per-op interpreter, bit for
+    bit (same accumulation order), and both match the oracle."""
+    case = "tiny_g_b2_all"
+    model, cfg, cams, seq, rt, heat, meta = build_model(case, emu_lib)
+    J, Z = cfg.DATASET.NUM_JOINTS, cfg.CAPTURE_SPEC.VOXELS_PER_AXIS[2]
+    z = torch.from_numpy(np.random.default_rng(8).random((7, J, Z), dtype=np.float32))
+    sd = dict(model.state_dict())
+    model.engine.fused_c2c = True
+    fused = model.pose_net.c2c_net(z)
+    model.engine.fused_c2c = False
+    generic = model.pose_net.c2c_net(z)
+    assert torch.equal(fused, generic)
+    np.testing.assert_allclose(fused.numpy(), O.c2c_net(sd, "pose_net.c2c_net", z).numpy(), rtol=3e-6, atol=3e-6)

@@ -185,3 +185,16 @@ def test_hipgraph_replay_equals_eager():
     o2 = [t.clone() for t in g(h2)[:3]]
     for a, b in zip(e1 + e2, o1 + o2):
         assert torch.equal(a, b)
+
+
+def test_fused_c2c_equals_generic_gpu():
+    """One-kernel C2CNet == per-op interpreter bit for bit at the Panoptic size (80 columns)."""
+    cfg = S.make_cfg("panoptic", device=DEV)
+    model, sd = build(cfg)
+    z = torch.from_numpy(np.random.default_rng(12).random((80, 15, 20), dtype=np.float32)).to(DEV)
+    model.engine.fused_c2c = True
+    fused = model.pose_net.c2c_net(z)
+    model.engine.fused_c2c = False
+    generic = model.pose_net.c2c_net(z)
+    model.engine.fused_c2c = True
+    assert torch.equal(fused, generic)
