@@ -474,42 +474,46 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
     // Software-pipelined operand fetch: the LDS reads of step s+1 (one tap of one channel pair:
     // CB A-words + PB B-words) are issued before the CB*PB MFMAs of step s; sched_barriers pin
     // that order (left alone, hipcc sinks every ds_read next to its MFMA and each MFMA eats a
-    // full LDS latency).  Two register sets; KK is odd for every kernel shape, so consecutive
+    // full LDS latency).  Two register sets; KH is odd for every kernel shape, so consecutive
     // channel pairs alternate the starting set (template parameter P).
-    float av[2][CB], bv[2][PB];
-    auto fetch = [&](int set, int ci, int tap, int wp) {
+    // Pipeline step = one kernel ROW of one channel pair (KW taps): its KW*(CB+PB) operand words are
+    // fetched while the previous row's KW*CB*PB MFMAs run.  Fetching a whole row per step lets the
+    // compiler pair neighbouring taps into ds_read2_b32 (B: adjacent floats; A: CBW apart) and needs
+    // one address add per (row, pixel block) instead of one per tap.
+    float av[2][KW][CB], bv[2][KW][PB];
+    auto fetch = [&](int set, int ci, int ky, int wp) {
       const int cic = ci < a.CC ? ci : a.CC - 2;              // last prefetch of a chunk: harmless re-read
-      const float* xs = Xs + (cic + half) * CS;
-      const float* ws = Ws + (cic + half) * KK * CBW + l31;
-      const int ky = tap / KW, kx = tap - ky * KW;
+      const float* xs = Xs + (cic + half) * CS + ky * wp;
+      const float* ws = Ws + (cic + half) * KK * CBW + ky * KW * CBW + l31;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) av[set][cb] = ws[tap * CBW + cb * 32];
+      for (int kx = 0; kx < KW; ++kx) {
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) bv[set][pb] = xs[poff[pb] + ky * wp + kx];
+        for (int cb = 0; cb < CB; ++cb) av[set][kx][cb] = ws[kx * CBW + cb * 32];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) bv[set][kx][pb] = xs[poff[pb] + kx];
+      }
     };
     auto block = [&](auto parity, int ci) {
       constexpr int P = decltype(parity)::value;
       int wp = WP;
       FVP_OPAQUE(wp);                                  // row addresses are recomputed per channel pair, not kept live
 #pragma unroll
-      for (int tap = 0; tap < KK; ++tap) {
-        const int cur = (P + tap) & 1, nxt = cur ^ 1;
-        // wait for this step's operands (issued one step ago) BEFORE issuing the next step's
-        // reads: hipcc only emits lgkmcnt(0), which placed after the new reads would expose
-        // their full LDS latency on every other step
+      for (int ky = 0; ky < KH; ++ky) {
+        const int cur = (P + ky) & 1, nxt = cur ^ 1;
+        // wait for this step's operands (issued one step ago) BEFORE issuing the next step's reads:
+        // hipcc only emits lgkmcnt(0), which placed after the new reads would expose their latency
         __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0), vmcnt/expcnt untouched
         __builtin_amdgcn_sched_barrier(0);
-        if (tap + 1 < KK) fetch(nxt, ci, tap + 1, wp);
+        if (ky + 1 < KH) fetch(nxt, ci, ky + 1, wp);
         else fetch(nxt, ci + 2, 0, wp);
         __builtin_amdgcn_sched_barrier(0);
-        const int kx = tap % KW;
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-          const float b = bv[cur][pb];
+        for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-            acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][cb], b, acc[cb][pb], 0, 0, 0);
-        }
+          for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][kx][cb], bv[cur][kx][pb], acc[cb][pb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
