@@ -62,6 +62,8 @@ struct ConvArgs {
   int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
   int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
   unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
+  int tpp, tpr_log2;  // Winograd: 2x2 tiles per plane band of a workgroup, log2(tiles per row)
+  unsigned m_tpp;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -539,6 +541,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   }
 }
 
+}  // namespace fvp
+#include "fvp_conv_wino.h"
+namespace fvp {
+
 // max_pool(2,2) / max_pool1d(2): one thread per output element.
 __global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ src, float* __restrict__ dst, long total,
                                                int H, int W, const uint8_t* __restrict__ plane_valid, int valid_div,
@@ -639,6 +645,84 @@ static const int kAblate = int(env_size("FVP_CONV_ABLATE", 0));
 static const int kForcePB = int(env_size("FVP_CONV_PB", 0));
 static const int kNoDma = int(env_size("FVP_CONV_NO_DMA", 0));
 
+static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
+static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
+
+// Shapes the Winograd kernel covers: 3x3, even H, W a power of two in [8, 64*4] with W/2 dividing
+// a wave's 32 tiles or vice versa.  Decided from the layer SHAPE only (never from the number of
+// planes), so a frame's result does not depend on the batch it is computed in.
+static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int* TN, int* TR) {
+  if (h < 2 || (h & 1) || w < 8 || (w & (w - 1)) || (coutp != 32 && coutp % 64 != 0) || cinp % 4 != 0) return false;
+  *WC = coutp == 32 ? 1 : 2;
+  *WT = 8 / *WC;
+  const int tpr = w / 2, TT = 16 * *WT, per_plane = (h / 2) * tpr;
+  if (TT % tpr != 0) return false;
+  if (per_plane >= TT) {
+    if (per_plane % TT != 0) return false;
+    *TN = 1;
+    *TR = TT / tpr;
+  } else {
+    if (TT % per_plane != 0) return false;
+    *TN = TT / per_plane;
+    *TR = h / 2;
+  }
+  return true;
+}
+
+static const int kWinoDiag = int(env_size("FVP_WINO_DIAG", 0));
+template <int WC, int WT, bool RES, int DIAG>
+static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr = false;
+  auto k = &k_conv_wino<WC, WT, RES, DIAG>;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return int(e);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);
+  return launch_status();
+}
+template <int WC, int WT>
+static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (kWinoDiag == 1) return launch_wino2<WC, WT, false, 1>(a, grid, lds, s);
+  if (kWinoDiag == 2) return launch_wino2<WC, WT, false, 2>(a, grid, lds, s);
+  if (kWinoDiag == 3) return launch_wino2<WC, WT, false, 3>(a, grid, lds, s);
+  if (a.flags & FVP_EPI_RES) return launch_wino2<WC, WT, true, 0>(a, grid, lds, s);
+  return launch_wino2<WC, WT, false, 0>(a, grid, lds, s);
+}
+
+static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
+  int WC, WT, TN, TR;
+  if (!wino_tiling(op.h, op.w, op.cinp, op.coutp, &WC, &WT, &TN, &TR)) return FVP_EINVAL;
+  a.wts = params + op.wino_off;
+  a.TN = TN;
+  a.TH = 2 * TR;
+  a.TW = op.w;
+  a.tiles_x = 1;
+  a.tiles_y = (op.h / 2) / TR;
+  a.tpp = TR * (op.w / 2);
+  a.m_tpp = make_magic(a.tpp);
+  a.tpr_log2 = __builtin_ctz(unsigned(op.w / 2));
+  a.vec = a.dma = 1;
+  a.zeros = params;
+  const int CBW = 32 * WC;
+  const size_t per_ch = (size_t(TN) * (a.TH + 2) * (op.w + 4) + size_t(CBW) * 16) * sizeof(float);
+  int CC = int((kWinoLdsBudget - 64) / (2 * per_ch)) & ~3;
+  if (CC > op.cinp) CC = op.cinp;
+  if (CC < 4) return FVP_ELIMIT;
+  while (CC > 4 && size_t(CC) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1 > 2048) CC -= 4;
+  for (int d = CC; d >= 4 && d * 2 > CC; d -= 4)
+    if (op.cinp % d == 0) { CC = d; break; }
+  a.CC = CC;
+  a.m_qpr = make_magic(op.w / 4 + 1);
+  a.m_rpc = make_magic(TN * (a.TH + 2));
+  a.m_thp = make_magic(a.TH + 2);
+  const size_t lds = 16 + 2 * (per_ch * CC + 16);
+  dim3 grid(a.tiles_y * ceil_div(planes, TN), op.coutp / CBW, 1);
+  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
+  return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s) : launch_wino<2, 4>(a, grid, lds, s);
+}
+
 // Tile selection: all couts per workgroup (CB = coutp/32), PB so that CB*PB <= 8 accumulator
 // tiles per wave, the tile shaped to cover full image rows where possible.
 static int plan_and_launch(const FvpConvOp& op, const float* params, float* const* bufs, int planes,
@@ -676,6 +760,8 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   if (double(planes) * std::max(op.cin, op.cout) * a.OH * a.OW >= 2147483648.0) return FVP_ELIMIT;
   const int CBfull = op.coutp / 32;
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
+  a.ablate = kAblate;
+  if (!tr && op.wino_off > 0 && !kNoWino) return plan_and_launch_wino(op, a, params, planes, s);
   // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
   // Large grids keep all couts in one workgroup (input tile staged once); small grids split
   // couts over blockIdx.y and shrink the pixel tile so that more CUs get work.
@@ -789,5 +875,10 @@ extern "C" int fvp_pack_conv(const float* weight, const float* bias, const float
   hipLaunchKernelGGL(k_pack_conv, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(s), weight, bias, bn_gamma,
                      bn_beta, bn_mean, bn_var, eps, transposed, op->cin, op->cout, op->cinp, op->coutp, op->kh,
                      op->kw, params + op->w_off, params + op->e_off);
+  if (op->wino_off > 0) {
+    FVP_REQUIRE(!transposed && op->kh == 3 && op->kw == 3);
+    hipLaunchKernelGGL(k_pack_wino, dim3(ceil_div(op->cinp * op->coutp, 256)), dim3(256), 0, as_stream(s), weight,
+                       op->cin, op->cout, op->cinp, op->coutp, params + op->wino_off);
+  }
   return launch_status();
 }

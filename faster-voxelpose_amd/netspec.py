@@ -58,6 +58,18 @@ class ParamTree(nn.Module):
         raise RuntimeError("ParamTree holds parameters only")
 
 
+def winograd_shape(kh, kw, h, w, cinp, coutp):
+    """3x3 layers the F(2x2,3x3) kernel covers (the same rule as wino_tiling() in
+    csrc/fvp_conv.hip): decided from the layer shape alone, never from the batch."""
+    if (kh, kw) != (3, 3) or h < 2 or h % 2 or w < 8 or w & (w - 1) or (coutp != 32 and coutp % 64) or cinp % 4:
+        return False
+    wt = 8 if coutp == 32 else 4
+    tpr, tt, per_plane = w // 2, 16 * wt, (h // 2) * (w // 2)
+    if tt % tpr:
+        return False
+    return per_plane % tt == 0 if per_plane >= tt else tt % per_plane == 0
+
+
 class StackSpec:
     """Op list + parameter keys of one conv stack (dim = 1 or 2)."""
 
@@ -180,14 +192,17 @@ class StackSpec:
         for i, o in enumerate(self.ops):
             cinp = _round_up(o["cin"], 2)
             coutp = _round_up(o["cout"], 32)
-            w_off = e_off = 0
+            w_off = e_off = wino_off = 0
             if o["kind"] != capi.OP_POOL2:
                 w_off = off
                 off += _round_up(cinp * o["kh"] * o["kw"] * coutp, 4)
                 e_off = off
-                off += 3 * coutp
+                off += _round_up(3 * coutp, 4)
+                if o["kind"] == capi.OP_CONV and winograd_shape(o["kh"], o["kw"], o["h"], o["w"], cinp, coutp):
+                    wino_off = off
+                    off += cinp * coutp * 16
             arr[i] = capi.FvpConvOp(o["kind"], o["src"], o["dst"], o["res"], o["cin"], o["cout"], o["kh"], o["kw"],
-                                    o["h"], o["w"], o["flags"], w_off, e_off, cinp, coutp)
+                                    o["h"], o["w"], o["flags"], w_off, e_off, cinp, coutp, wino_off)
         self.nparams = off
         self.op_array = arr
         return self

@@ -144,6 +144,9 @@ typedef struct FvpConvOp {
   int32_t w_off;              /* float offset of packed weights in `params`                 */
   int32_t e_off;              /* float offset of epilogue vectors bias|scale|shift, 3*coutp */
   int32_t cinp, coutp;        /* padded counts used by the packed layout                    */
+  int32_t wino_off;           /* 0, or float offset of the Winograd-domain copy of a 3x3    */
+                              /* conv's weights ([cinp][coutp][16]); when set the conv runs  */
+                              /* as F(2x2,3x3) (requires even H, W a power of two)           */
 } FvpConvOp;
 
 /* bufs[i] = device pointer of activation buffer i (caller sized: planes*C*H*W floats).

@@ -132,6 +132,29 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D reg r: row 4*(l>>4)+r, col l&15
+static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  uint32_t mine[2];
+  memcpy(&mine[0], &a, 4);
+  memcpy(&mine[1], &b, 4);
+  uint32_t all[64][4];
+  hipemu::wave_exchange(mine, 2, all);
+  const int l = hipemu::cur->lane, col = l & 15, g = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * g + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      memcpy(&av, &all[row + 16 * k][0], 4);
+      memcpy(&bv, &all[col + 16 * k][1], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  hipemu::wave_exchange_done();
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
 
 // LDS-DMA: wave-uniform LDS base + lane * size, per-lane global source
 static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* l,

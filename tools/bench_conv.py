@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--net", default="conv_net")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ops", default="", help="comma-separated op indices (default: all)")
     args = ap.parse_args()
     dev = "cuda:0"
     cfg = S.make_cfg("panoptic", device=dev, min_score=-1.0)
@@ -37,7 +38,10 @@ def main():
     lib = e.lib
     tot = 0.0
     print(f"{args.net}: {planes} planes   env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FVP_")))
+    only = {int(x) for x in args.ops.split(",") if x}
     for i, op in enumerate(spec.ops):
+        if only and i not in only:
+            continue
         one = (capi.FvpConvOp * 1)(spec.op_array[i])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(args.iters + 1):
