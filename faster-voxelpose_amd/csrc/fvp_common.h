@@ -18,6 +18,26 @@ __device__ __forceinline__ float bn_affine(float acc, float bias, float scale, f
   return __fmaf_rn(acc + bias, scale, shift);
 }
 
+// s_waitcnt vmcnt(n) with lgkmcnt / expcnt left alone (simm16: vmcnt[3:0] | expcnt 7<<4 | lgkmcnt 15<<8)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+  }
+}
+
 inline hipStream_t as_stream(fvp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Kernel-class timing used by bench.py's roofline leg (fvp_prof_*).

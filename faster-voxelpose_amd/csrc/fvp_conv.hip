@@ -63,6 +63,7 @@ struct ConvArgs {
   int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
   unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
   int tpp, tpr_log2;  // Winograd: 2x2 tiles per plane band of a workgroup, log2(tiles per row)
+  int wino_ni;        // Winograd: input DMA rounds (of 512 x 16 B) per chunk
   unsigned m_tpp;
 };
 
@@ -669,11 +670,10 @@ static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int
   return true;
 }
 
-static const int kWinoDiag = int(env_size("FVP_WINO_DIAG", 0));
-template <int WC, int WT, bool RES, int DIAG>
+template <int WC, int WT, int CC, bool RES>
 static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr = false;
-  auto k = &k_conv_wino<WC, WT, RES, DIAG>;
+  auto k = &k_conv_wino<WC, WT, CC, RES>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return int(e);
@@ -684,11 +684,9 @@ static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s)
 }
 template <int WC, int WT>
 static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  if (kWinoDiag == 1) return launch_wino2<WC, WT, false, 1>(a, grid, lds, s);
-  if (kWinoDiag == 2) return launch_wino2<WC, WT, false, 2>(a, grid, lds, s);
-  if (kWinoDiag == 3) return launch_wino2<WC, WT, false, 3>(a, grid, lds, s);
-  if (a.flags & FVP_EPI_RES) return launch_wino2<WC, WT, true, 0>(a, grid, lds, s);
-  return launch_wino2<WC, WT, false, 0>(a, grid, lds, s);
+  const bool res = a.flags & FVP_EPI_RES;
+  if (a.CC == 8) return res ? launch_wino2<WC, WT, 8, true>(a, grid, lds, s) : launch_wino2<WC, WT, 8, false>(a, grid, lds, s);
+  return res ? launch_wino2<WC, WT, 4, true>(a, grid, lds, s) : launch_wino2<WC, WT, 4, false>(a, grid, lds, s);
 }
 
 static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
@@ -706,18 +704,25 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   a.vec = a.dma = 1;
   a.zeros = params;
   const int CBW = 32 * WC;
-  const size_t per_ch = (size_t(TN) * (a.TH + 2) * (op.w + 4) + size_t(CBW) * 16) * sizeof(float);
-  int CC = int((kWinoLdsBudget - 64) / (2 * per_ch)) & ~3;
-  if (CC > op.cinp) CC = op.cinp;
-  if (CC < 4) return FVP_ELIMIT;
-  while (CC > 4 && size_t(CC) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1 > 2048) CC -= 4;
-  for (int d = CC; d >= 4 && d * 2 > CC; d -= 4)
-    if (op.cinp % d == 0) { CC = d; break; }
+  // channels per chunk: 8 when it divides cinp and three slots fit, else 4
+  auto slot_bytes = [&](int cc, int* ni) {
+    const size_t quads = size_t(cc) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1;
+    *ni = int((quads + 511) / 512);
+    return size_t(*ni) * 8192 + size_t(cc) * CBW * 64;
+  };
+  int CC = op.cinp % 8 == 0 ? 8 : 4, ni = 0;
+  size_t slot = slot_bytes(CC, &ni);
+  if (CC == 8 && (3 * slot + 64 > kWinoLdsBudget || ni > 4)) {
+    CC = 4;
+    slot = slot_bytes(CC, &ni);
+  }
+  if (3 * slot + 64 > kWinoLdsBudget || ni > 4) return FVP_ELIMIT;
   a.CC = CC;
+  a.wino_ni = ni;
   a.m_qpr = make_magic(op.w / 4 + 1);
   a.m_rpc = make_magic(TN * (a.TH + 2));
   a.m_thp = make_magic(a.TH + 2);
-  const size_t lds = 16 + 2 * (per_ch * CC + 16);
+  const size_t lds = 16 + 3 * slot;
   dim3 grid(a.tiles_y * ceil_div(planes, TN), op.coutp / CBW, 1);
   ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s) : launch_wino<2, 4>(a, grid, lds, s);

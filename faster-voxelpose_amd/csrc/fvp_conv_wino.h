@@ -16,7 +16,7 @@
 // bias/BN/residual/ReLU epilogue are pure per-lane arithmetic, stored as float2 rows.
 //
 // Workgroup = 8 waves = WC cout blocks (32) x WT tile blocks (16).  LDS per chunk of CC channels
-// (double buffered, filled by the LDS-DMA exactly like k_conv_dma):
+// (three slots filled by the LDS-DMA two chunks ahead; layout as in k_conv_dma):
 //   Xs[CC][TN][TH+2][4 + W]   zero-margin dense rows (halo reads need no masking)
 //   Ws[CC][32*WC][16]         quad q of row `co` stored at quad q ^ ((co>>2)&3): the four
 //                             ds_read_b128 of a lane (xi = 0..3) are bank-conflict free unpadded
@@ -25,19 +25,40 @@
 namespace fvp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int WC, int WT, bool HAS_RES, int DIAG = 0>
+// Column pass of the input transform on register pairs E = (t0, t3), M = (t1, t2):
+//   v03 = (t0 - t2, t1 - t3)   v12 = (t1 + t2, t2 - t1)
+// one packed add each (the half swaps and sign flips are operand modifiers of v_pk_add_f32).
+__device__ __forceinline__ void wino_cols(f32x2 E, f32x2 M, f32x2& v03, f32x2& v12) {
+#if defined(__AMDGCN__)
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v03) : "v"(E), "v"(M));
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(M));
+#else
+  v03 = f32x2{E.x - M.y, M.x - E.y};
+  v12 = f32x2{M.x + M.y, M.y - M.x};
+#endif
+}
+
+// CC = channels per LDS chunk (4 or 8, divides cinp): the steps of a chunk are unrolled so that
+// every weight read is `chunk base + immediate`.
+template <int WC, int WT, int CC, bool HAS_RES>
 __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
   static_assert(WC * WT == 8, "8 waves");
+  static_assert(CC == 4 || CC == 8, "chunk");
   constexpr int CBW = 32 * WC;
+  constexpr int WS_SZ = CC * CBW * 16;               // floats of one weight chunk
+  constexpr int NW = CC * WC / 4;                    // weight DMA instructions per wave per chunk
+  constexpr int S = CC / 4;                          // steps (4 channels) per chunk
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int k4 = lane >> 4, l15 = lane & 15;
   const int wc = wave % WC, wt = wave / WC;
   const int THp = a.TH + 2, W = a.W, WP = W + 4;
   const int plane_sz = THp * WP;
   const int CS = a.TN * plane_sz;
-  const int xs_sz = a.CC * CS + 4, ws_sz = a.CC * CBW * 16, buf_sz = xs_sz + ws_sz;   // floats, all % 4 == 0
+  const int xs_sz = a.wino_ni * 2048;                // input slot, padded to whole DMA rounds (floats)
+  const int buf_sz = xs_sz + WS_SZ;
 
   const int tile = blockIdx.x;
   const int pg = tile / a.tiles_y;
@@ -57,7 +78,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   const int swz = (l15 >> 2) & 3;
   int aoff[4];                                       // cout block cb adds 16 rows = 256 floats
 #pragma unroll
-  for (int xi = 0; xi < 4; ++xi) aoff[xi] = ((k4 * CBW + wc * 32 + l15) * 4 + (xi ^ swz)) * 4;
+  for (int xi = 0; xi < 4; ++xi) aoff[xi] = xs_sz + ((k4 * CBW + wc * 32 + l15) * 4 + (xi ^ swz)) * 4;
 
   f32x4 acc[2][16];
 #pragma unroll
@@ -70,16 +91,16 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   const int HW = a.H * W;
   const int qpr = (W >> 2) + 1;
   const int rows_per_ch = a.TN * THp;
-  const int nin = a.CC * rows_per_ch * qpr + 1;
-  const int nwq = a.CC * CBW * 4;
-  const int nchunks = (a.cinp + a.CC - 1) / a.CC;
+  const int nin = CC * rows_per_ch * qpr + 1;        // + the zero quad behind the last row
+  const int nchunks = a.cinp / CC;
+  const int nps = a.wino_ni + NW;                    // DMA instructions per wave per chunk (uniform)
 
-  constexpr int kMaxIn = 4;                          // host guarantees nin <= kMaxIn * 512
+  constexpr int kMaxIn = 4;                          // host guarantees wino_ni <= kMaxIn
   int in_off[kMaxIn], in_ci[kMaxIn];
 #pragma unroll
   for (int j = 0; j < kMaxIn; ++j) {
     const int it = (wave + 8 * j) * 64 + lane;
-    in_off[j] = -1;
+    in_off[j] = -1;                                  // zero page: margins, halo rows, padding items
     in_ci[j] = 0;
     if (it < nin) {
       const int row = fdiv(it, a.m_qpr), qd = it - row * qpr;
@@ -88,19 +109,20 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       const int n = fdiv(rem, a.m_thp), ry = rem - n * THp;
       const int plane = plane0 + n, y = y0 + ry - 1;
       in_ci[j] = ci;
-      if (qd > 0 && ci < a.CC && plane < a.planes && y >= 0 && y < a.H)
+      if (qd > 0 && ci < CC && plane < a.planes && y >= 0 && y < a.H)
         in_off[j] = (n * a.cin + ci) * HW + y * W + 4 * (qd - 1);
     }
   }
   const float* src_tile = a.src + size_t(plane0) * a.cin * HW;
-  auto stage = [&](int k, int buf) {
-    float* xs = smem + 4 + buf * buf_sz;
+  // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
+  auto stage = [&](int k, int boff) {
+    float* xs = smem + 4 + boff;
     float* ws = xs + xs_sz;
-    const int c0 = k * a.CC;
+    const int c0 = k * CC;
 #pragma unroll
     for (int j = 0; j < kMaxIn; ++j) {
-      const int g = wave + 8 * j;
-      if (g * 64 + lane < nin) {
+      if (j < a.wino_ni) {
+        const int g = wave + 8 * j;
         const bool ok = in_off[j] >= 0 && c0 + in_ci[j] < a.cin;
         const float* src = ok ? src_tile + size_t(c0) * HW + in_off[j] : a.zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -108,98 +130,103 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       }
     }
     const float* gw = wts + size_t(c0) * a.coutp * 16;
-    for (int g = wave; g * 64 < nwq; g += 8) {       // nwq is a multiple of 64
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int g = wave + 8 * j;
       const int it = g * 64 + lane;
       const int ci = it / (CBW * 4), qd = it - ci * (CBW * 4);
-      const float* src = c0 + ci < a.cinp ? gw + size_t(ci) * a.coutp * 16 + 4 * qd : a.zeros;
+      const float* src = gw + size_t(ci) * a.coutp * 16 + 4 * qd;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(ws + g * 256), 16, 0, 0);
     }
   };
 
-  if (!(a.ablate & 1)) stage(0, 0);
+  // ---- operand fetch / transform / MFMA building blocks
+  float4 av[2][4];
+  f32x2 dM[4], dE[4];                                // patch rows as pairs (d1,d2) and (d0,d3)
+  f32x2 v03[4], v12[4];                              // V[xi][0],V[xi][3] and V[xi][1],V[xi][2]
+  auto fetch_a = [&](int cb, const float* base, int s) {      // base = chunk slot, s = step in chunk
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+      av[cb][xi] = *reinterpret_cast<const float4*>(base + aoff[xi] + (s * 4 * CBW * 16 + cb * 256));
+  };
+  auto fetch_d = [&](const float* base, int s, int wp) {
+    const float* xs = base + poff + s * 4 * CS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = xs + r * wp;
+      dM[r] = *reinterpret_cast<const f32x2*>(row + 1);       // 8-byte aligned: column 4 + 2*tx
+      dE[r] = f32x2{row[0], row[3]};
+    }
+  };
+  auto transform_rows = [&](f32x2 (&tM)[4], f32x2 (&tE)[4]) {  // B^T d
+    tM[0] = dM[0] - dM[2];  tE[0] = dE[0] - dE[2];
+    tM[1] = dM[1] + dM[2];  tE[1] = dE[1] + dE[2];
+    tM[2] = dM[2] - dM[1];  tE[2] = dE[2] - dE[1];
+    tM[3] = dM[1] - dM[3];  tE[3] = dE[1] - dE[3];
+  };
+  auto mfma16 = [&](int cb) {
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      acc[cb][4 * xi + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].x, v03[xi].x, acc[cb][4 * xi + 0], 0, 0, 0);
+      acc[cb][4 * xi + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].y, v12[xi].x, acc[cb][4 * xi + 1], 0, 0, 0);
+      acc[cb][4 * xi + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].z, v12[xi].y, acc[cb][4 * xi + 2], 0, 0, 0);
+      acc[cb][4 * xi + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].w, v03[xi].y, acc[cb][4 * xi + 3], 0, 0, 0);
+    }
+  };
+
+  // ---- three chunk slots: chunk k+2 streams in while chunk k is consumed
+  const bool dma = !(a.ablate & 1);
+  if (dma) {
+    stage(0, 0);
+    if (nchunks > 1) stage(1, buf_sz);
+    wait_vmcnt(nchunks > 1 ? nps : 0);
+  }
   __syncthreads();
+  int cur_off = 0;
+  fetch_a(0, smem + 4, 0);
+  fetch_d(smem + 4, 0, WP);
   for (int k = 0; k < nchunks; ++k) {
-    const int buf = k & 1;
-    if (k + 1 < nchunks && !(a.ablate & 1)) stage(k + 1, buf ^ 1);
-    const float* Xs = smem + 4 + buf * buf_sz;
-    const float* Ws = Xs + xs_sz;
-    // One step = 4 channels = two half-steps (cout block 0 / 1) of 16 MFMAs each.  The weight
-    // quads of the NEXT half-step and the patch of the NEXT step are in flight while the
-    // current MFMAs run; the patch transform (32 adds) is interleaved with them.
-    float4 av[2][4];
-    float dv[4][4];
-    float vv[4][4];
-    auto fetch_a = [&](int cb, int ci) {
-      const int cic = ci < a.CC ? ci : a.CC - 4;     // last prefetch of a chunk: harmless re-read
-      const float* ws = Ws + cic * (CBW * 16) + cb * 256;
+    const int nxt_off = cur_off + buf_sz >= 3 * buf_sz ? 0 : cur_off + buf_sz;
+    const int nn_off = nxt_off + buf_sz >= 3 * buf_sz ? 0 : nxt_off + buf_sz;
+    if (k + 2 < nchunks && dma) stage(k + 2, nn_off);
+    const float* cur = smem + 4 + cur_off;
+    const float* nxt = smem + 4 + nxt_off;
+    int wp = WP;
+    FVP_OPAQUE(wp);
 #pragma unroll
-      for (int xi = 0; xi < 4; ++xi) av[cb][xi] = *reinterpret_cast<const float4*>(ws + aoff[xi]);
-    };
-    auto fetch_d = [&](int ci, int wp) {
-      const int cic = ci < a.CC ? ci : a.CC - 4;
-      const float* xs = Xs + cic * CS + poff;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* row = xs + r * wp;
-        const float2 mid = *reinterpret_cast<const float2*>(row + 1);   // 8-byte aligned: 4 + 2*tx
-        dv[r][0] = row[0];
-        dv[r][1] = mid.x;
-        dv[r][2] = mid.y;
-        dv[r][3] = row[3];
-      }
-    };
-    auto mfma16 = [&](int cb) {
-#pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {
-        acc[cb][4 * xi + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].x, vv[xi][0], acc[cb][4 * xi + 0], 0, 0, 0);
-        acc[cb][4 * xi + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].y, vv[xi][1], acc[cb][4 * xi + 1], 0, 0, 0);
-        acc[cb][4 * xi + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].z, vv[xi][2], acc[cb][4 * xi + 2], 0, 0, 0);
-        acc[cb][4 * xi + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].w, vv[xi][3], acc[cb][4 * xi + 3], 0, 0, 0);
-      }
-    };
-    fetch_a(0, 0);
-    fetch_d(0, WP);
-    for (int ci = (a.ablate & 4) ? a.CC : 0; ci < a.CC; ci += 4) {
-      int wp = WP;
-      FVP_OPAQUE(wp);
-      // ---- half-step 0: transform the patch, cout block 0
-      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): av[0] and dv have landed
+    for (int s = 0; s < S; ++s) {
+      // ---- half-step 0: patch transform, cout block 0
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): av[0] and the patch have landed
       __builtin_amdgcn_sched_barrier(0);
-      if (!(DIAG & 2)) fetch_a(1, ci);
+      fetch_a(1, cur, s);
       __builtin_amdgcn_sched_barrier(0);             // issue the reads now: left alone hipcc sinks them below the MFMAs
-      float tt[4][4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {                  // B^T d
-        tt[0][c] = dv[0][c] - dv[2][c];
-        tt[1][c] = dv[1][c] + dv[2][c];
-        tt[2][c] = dv[2][c] - dv[1][c];
-        tt[3][c] = dv[1][c] - dv[3][c];
-      }
-      if (!(DIAG & 2)) fetch_d(ci + 4, wp);                           // dv is dead from here: refill for the next step
+      f32x2 tM[4], tE[4];
+      transform_rows(tM, tE);
+      if (s + 1 < S) fetch_d(cur, s + 1, wp);        // the patch registers are dead: refill for the next step
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {               // (B^T d) B
-        if (DIAG & 1) {
-          vv[xi][0] = dv[xi][0]; vv[xi][1] = dv[xi][1]; vv[xi][2] = dv[xi][2]; vv[xi][3] = dv[xi][3];
-        } else {
-        vv[xi][0] = tt[xi][0] - tt[xi][2];
-        vv[xi][1] = tt[xi][1] + tt[xi][2];
-        vv[xi][2] = tt[xi][2] - tt[xi][1];
-        vv[xi][3] = tt[xi][1] - tt[xi][3];
-        }
-      }
+      for (int xi = 0; xi < 4; ++xi) wino_cols(tE[xi], tM[xi], v03[xi], v12[xi]);
       mfma16(0);
       __builtin_amdgcn_sched_barrier(0);
-      // ---- half-step 1: cout block 1
-      __builtin_amdgcn_s_waitcnt(0xc07f);            // av[1] (and the next patch) have landed
+      // ---- half-step 1: cout block 1; the last one of a chunk crosses into the next slot
+      __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(DIAG & 2)) fetch_a(0, ci + 4);
+      if (s + 1 < S) {
+        fetch_a(0, cur, s + 1);
+      } else {
+        // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
+        // may be overwritten by the DMA of chunk k+3, and chunk k+1 has landed for everybody
+        if (dma) wait_vmcnt(k + 2 < nchunks ? nps : 0);
+        __syncthreads();
+        fetch_a(0, nxt, 0);
+        fetch_d(nxt, 0, wp);
+      }
       __builtin_amdgcn_sched_barrier(0);
       mfma16(1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    cur_off = nxt_off;
   }
 
   if (a.ablate & 8) return;
