@@ -30,7 +30,7 @@ class FvpConvOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32), ("res", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("h", C.c_int32), ("w", C.c_int32), ("flags", C.c_int32), ("w_off", C.c_int32),
-                ("e_off", C.c_int32), ("cinp", C.c_int32), ("coutp", C.c_int32), ("wino_off", C.c_int32)]
+                ("e_off", C.c_int32), ("cinp", C.c_int32), ("coutp", C.c_int32), ("wino_off", C.c_int32), ("pair_off", C.c_int32)]
 
 
 _P = C.c_void_p

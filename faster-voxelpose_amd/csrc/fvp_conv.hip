@@ -297,6 +297,57 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     conv_epilogue<CB, PB, false>(a, acc, wave, l31, half, plane0, y0, x0, co0, tapT);
 }
 
+// Epilogue of the PAIR layout: accumulator rows co / 16+co of a lane are pixels 2j / 2j+1 of the
+// same cout -> one float2 store per cout, 256 contiguous bytes per 32 lanes.
+template <int PB, bool HAS_RES>
+__device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x16 (&acc)[PB], int wave, int l31, int half,
+                                                   int plane0, int y0) {
+  const float* bias = a.epi;
+  const float* scale = a.epi + a.coutp;
+  const float* shift = a.epi + 2 * a.coutp;
+  const bool relu = a.flags & FVP_EPI_RELU;
+  const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
+  const int Wq = a.W >> 1;
+  const int tile_px = a.TN * a.TH * Wq;
+  const int HW = a.H * a.W;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int q = (wave * PB + pb) * 32 + l31;
+    const int qc = q < tile_px ? q : 0;
+    const int n = fdiv(qc, a.m_thw), r2 = qc - n * (a.TH * Wq);
+    const int ty = fdiv(r2, a.m_w), tx = r2 - ty * Wq;
+    const int plane = plane0 + n, y = y0 + ty;
+    const bool pix_ok = q < tile_px && plane < a.planes && y < a.H;
+    const unsigned pix = pix_ok ? unsigned(y * a.W + 2 * tx) : 0u;
+    const unsigned pbase = pix_ok ? unsigned(plane) * a.cout : 0u;
+    float2 rv[8];
+    unsigned o[8];
+    bool ok[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;           // 0..15
+      ok[r] = pix_ok && co < a.cout;
+      o[r] = (pbase + (ok[r] ? co : 0)) * unsigned(HW) + pix;
+      if (HAS_RES) rv[r] = *reinterpret_cast<const float2*>(a.res + o[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v[2] = {acc[pb][r], acc[pb][r + 8]};
+      const float rr[2] = {HAS_RES ? rv[r].x : 0.f, HAS_RES ? rv[r].y : 0.f};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float x = bn_affine(v[e], bias[co], scale[co], shift[co]);
+        if (HAS_RES && !res_after) x += rr[e];
+        if (relu) x = fmaxf(x, 0.0f);
+        if (HAS_RES && res_after) x += rr[e];
+        v[e] = x;
+      }
+      if (ok[r]) *reinterpret_cast<float2*>(a.dst + o[r]) = make_float2(v[0], v[1]);
+    }
+  }
+}
+
 // Wide epilogue for stride-1 outputs of the pipelined kernel: each 32x32 accumulator tile goes
 // through a 4 KB per-wave LDS scratch so that a lane ends up with 4 consecutive pixels of one
 // channel -> dwordx4 residual loads and dwordx4 stores in 128-byte runs (the MFMA layout gives a
@@ -370,10 +421,17 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&a
 //                                  without any per-operand masking; rows above / below the image,
 //                                  channel padding and missing planes also read the zero page
 //   Ws[buf][CC][KH*KW][32*CB]
-template <int KH, int KW, int CB, int PB>
+//
+// PAIR (layers with cout <= 16, i.e. the 7x7 front conv 15 -> 16): instead of padding the couts
+// to the 32 rows of the MFMA tile, rows 16..31 hold the SAME couts with the kernel shifted one
+// tap to the right, and a tile column is a pixel PAIR: row co computes pixel 2j, row 16+co pixel
+// 2j+1, over KW+1 taps (the extra tap of each row set has a zero weight, which leaves the fma
+// chain bit-identical).  7/8 of the MFMA work is useful instead of 1/2.
+template <int KH, int KW, int CB, int PB, bool PAIR = false>
 __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
-  constexpr int KK = KH * KW;
+  constexpr int KT = PAIR ? KW + 1 : KW;             // taps per kernel row in the packed layout
+  constexpr int KK = KH * KT;
   constexpr int CBW = 32 * CB;
   constexpr int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -393,15 +451,16 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   const int tapT = blockIdx.z;
   const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp + co0;
 
-  const int tile_px = a.TN * a.TH * a.TW;
+  const int Wq = PAIR ? W >> 1 : W;                  // tile columns per image row (pixels or pixel pairs)
+  const int tile_px = a.TN * a.TH * Wq;
   int poff[PB];
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int q = (wave * PB + pb) * 32 + l31;
     const int qc = q < tile_px ? q : 0;
-    const int n = fdiv(qc, a.m_thw), r = qc - n * (a.TH * W);
-    const int ty = fdiv(r, a.m_w), tx = r - ty * W;
-    poff[pb] = n * plane_sz + ty * WP + 4 + tx - padW;
+    const int n = fdiv(qc, a.m_thw), r = qc - n * (a.TH * Wq);
+    const int ty = fdiv(r, a.m_w), tx = r - ty * Wq;
+    poff[pb] = n * plane_sz + ty * WP + 4 + (PAIR ? 2 * tx : tx) - padW;
   }
 
   f32x16 acc[CB][PB];
@@ -483,13 +542,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
     // fetched while the previous row's KW*CB*PB MFMAs run.  Fetching a whole row per step lets the
     // compiler pair neighbouring taps into ds_read2_b32 (B: adjacent floats; A: CBW apart) and needs
     // one address add per (row, pixel block) instead of one per tap.
-    float av[2][KW][CB], bv[2][KW][PB];
+    float av[2][KT][CB], bv[2][KT][PB];
     auto fetch = [&](int set, int ci, int ky, int wp) {
       const int cic = ci < a.CC ? ci : a.CC - 2;              // last prefetch of a chunk: harmless re-read
       const float* xs = Xs + (cic + half) * CS + ky * wp;
-      const float* ws = Ws + (cic + half) * KK * CBW + ky * KW * CBW + l31;
+      const float* ws = Ws + (cic + half) * KK * CBW + ky * KT * CBW + l31;
 #pragma unroll
-      for (int kx = 0; kx < KW; ++kx) {
+      for (int kx = 0; kx < KT; ++kx) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) av[set][kx][cb] = ws[kx * CBW + cb * 32];
 #pragma unroll
@@ -511,7 +570,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
         else fetch(nxt, ci + 2, 0, wp);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx)
+        for (int kx = 0; kx < KT; ++kx)
 #pragma unroll
           for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
@@ -530,7 +589,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
     __syncthreads();
   }
   if (a.ablate & 8) return;
-  if (a.ntapT > 1 || (a.ablate & 16)) {          // transposed conv: strided outputs, scalar stores
+  if (PAIR) {
+    if (a.flags & FVP_EPI_RES)
+      conv_epilogue_pair<PB, true>(a, acc[0], wave, l31, half, plane0, y0);
+    else
+      conv_epilogue_pair<PB, false>(a, acc[0], wave, l31, half, plane0, y0);
+  } else if (a.ntapT > 1 || (a.ablate & 16)) {          // transposed conv: strided outputs, scalar stores
     if (a.flags & FVP_EPI_RES)
       conv_epilogue<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
     else
@@ -602,6 +666,24 @@ k_pack_conv(const float* __restrict__ w, const float* __restrict__ b, const floa
   }
 }
 
+// PAIR layout of a KHxKW conv with cout <= 16: [cinp][KH][KW+1][32], row co = w[co][ci][ky][kx]
+// (kx < KW), row 16+co = w[co][ci][ky][kx-1] (kx >= 1), zero elsewhere.
+__global__ void __launch_bounds__(256)
+k_pack_pair(const float* __restrict__ w, int cin, int cout, int cinp, int kh, int kw, float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int kt = kw + 1;
+  if (i >= cinp * kh * kt * 32) return;
+  const int row = i & 31;
+  int r = i >> 5;
+  const int kx = r % kt;
+  r /= kt;
+  const int ky = r % kh, ci = r / kh;
+  const int co = row & 15, sx = row < 16 ? kx : kx - 1;
+  float v = 0.0f;
+  if (co < cout && ci < cin && sx >= 0 && sx < kw) v = w[((size_t(co) * cin + ci) * kh + ky) * kw + sx];
+  dst[i] = v;
+}
+
 template <int KH, int KW, int CB, int PB>
 static int launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   if (a.dma) {
@@ -647,6 +729,7 @@ static const int kForcePB = int(env_size("FVP_CONV_PB", 0));
 static const int kNoDma = int(env_size("FVP_CONV_NO_DMA", 0));
 
 static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
+static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
 
 // Shapes the Winograd kernel covers: 3x3, even H, W a power of two in [8, 64*4] with W/2 dividing
@@ -770,7 +853,10 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
   // Large grids keep all couts in one workgroup (input tile staged once); small grids split
   // couts over blockIdx.y and shrink the pixel tile so that more CUs get work.
-  const int hw = op.h * op.w;
+  // PAIR layout (cout <= 16): tile columns are pixel pairs
+  const bool pair = !tr && op.pair_off > 0 && !kNoPair && op.w % 4 == 0;
+  const int wq = pair ? op.w / 2 : op.w;           // tile columns per image row
+  const int hw = op.h * wq;
   const long px_total = long(hw) * planes;
   int CB = CBfull, PB = 4 / CBfull;
   if (px_total / (128 * PB) < 512) {
@@ -785,17 +871,17 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
     a.TW = op.w;
     a.TH = op.h;
     a.TN = TP / hw > 0 ? TP / hw : 1;
-  } else if (op.w <= TP) {              // full-width row bands
+  } else if (wq <= TP) {                // full-width row bands
     a.TW = op.w;
-    a.TH = TP / op.w;
+    a.TH = TP / wq;
     a.TN = 1;
   } else {
     a.TW = TP;
     a.TH = 1;
     a.TN = 1;
   }
-  a.m_w = make_magic(a.TW);
-  a.m_thw = make_magic(a.TH * a.TW);
+  a.m_w = make_magic(pair ? wq : a.TW);
+  a.m_thw = make_magic(a.TH * (pair ? wq : a.TW));
   a.tiles_x = ceil_div(op.w, a.TW);
   a.tiles_y = ceil_div(op.h, a.TH);
   const int pgroups = ceil_div(planes, a.TN);
@@ -804,7 +890,8 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   a.dma = (a.vec && !kNoDma) ? 1 : 0;
   a.zeros = params;
   const int twp = a.dma ? a.TW + 4 : (a.vec ? a.TW + 8 : a.TW + kw - 1);
-  const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * twp + size_t(kh) * kw * 32 * CB) * sizeof(float);
+  const int kt = pair ? kw + 1 : kw;               // taps per kernel row in the packed layout
+  const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * twp + size_t(kh) * kt * 32 * CB) * sizeof(float);
   // the pipelined kernel keeps two chunks in LDS
   int CC = int((kLdsBudget - 64) / (per_ch * (a.dma ? 2 : 1))) & ~1;
   if (CC > op.cinp) CC = op.cinp;
@@ -819,11 +906,22 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   a.m_thp = make_magic(a.TH + kh - 1);
   const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * twp + 3) & ~size_t(3);
   const size_t lds = a.dma ? std::max<size_t>(16 + 2 * (per_ch * CC + 16), 16 + 16384)
-                           : (xs_floats + size_t(CC) * kh * kw * 32 * CB) * sizeof(float);
+                           : (xs_floats + size_t(CC) * kh * kt * 32 * CB) * sizeof(float);
   dim3 grid(a.tiles_x * a.tiles_y * pgroups, CBfull / CB, a.ntapT);
   // algorithmic FLOPs (2*MAC on the true channel counts)
   const double taps = tr ? double(a.ntapT) : double(op.kh * op.kw);
-  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * hw * planes, 1, prof_level() >= 2);
+  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * op.h * op.w * planes, 1, prof_level() >= 2);
+  if (pair) {
+    if (!a.dma || CB != 1 || kh != 7 || kw != 7) return FVP_ELIMIT;
+    a.wts = params + op.pair_off;
+    switch (PB) {
+      case 1: hipLaunchKernelGGL((k_conv_dma<7, 7, 1, 1, true>), grid, dim3(256), lds, s, a); break;
+      case 2: hipLaunchKernelGGL((k_conv_dma<7, 7, 1, 2, true>), grid, dim3(256), lds, s, a); break;
+      case 4: hipLaunchKernelGGL((k_conv_dma<7, 7, 1, 4, true>), grid, dim3(256), lds, s, a); break;
+      default: return FVP_ELIMIT;
+    }
+    return launch_status();
+  }
   return dispatch_conv(kh, kw, CB, PB, a, grid, lds, s);
 }
 
@@ -880,6 +978,11 @@ extern "C" int fvp_pack_conv(const float* weight, const float* bias, const float
   hipLaunchKernelGGL(k_pack_conv, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(s), weight, bias, bn_gamma,
                      bn_beta, bn_mean, bn_var, eps, transposed, op->cin, op->cout, op->cinp, op->coutp, op->kh,
                      op->kw, params + op->w_off, params + op->e_off);
+  if (op->pair_off > 0) {
+    FVP_REQUIRE(!transposed && op->cout <= 16 && op->coutp == 32);
+    hipLaunchKernelGGL(k_pack_pair, dim3(ceil_div(op->cinp * op->kh * (op->kw + 1) * 32, 256)), dim3(256), 0,
+                       as_stream(s), weight, op->cin, op->cout, op->cinp, op->kh, op->kw, params + op->pair_off);
+  }
   if (op->wino_off > 0) {
     FVP_REQUIRE(!transposed && op->kh == 3 && op->kw == 3);
     hipLaunchKernelGGL(k_pack_wino, dim3(ceil_div(op->cinp * op->coutp, 256)), dim3(256), 0, as_stream(s), weight,

@@ -192,7 +192,7 @@ class StackSpec:
         for i, o in enumerate(self.ops):
             cinp = _round_up(o["cin"], 2)
             coutp = _round_up(o["cout"], 32)
-            w_off = e_off = wino_off = 0
+            w_off = e_off = wino_off = pair_off = 0
             if o["kind"] != capi.OP_POOL2:
                 w_off = off
                 off += _round_up(cinp * o["kh"] * o["kw"] * coutp, 4)
@@ -201,8 +201,12 @@ class StackSpec:
                 if o["kind"] == capi.OP_CONV and winograd_shape(o["kh"], o["kw"], o["h"], o["w"], cinp, coutp):
                     wino_off = off
                     off += cinp * coutp * 16
+                if (o["kind"] == capi.OP_CONV and (o["kh"], o["kw"]) == (7, 7) and o["cout"] <= 16
+                        and o["w"] % 4 == 0):
+                    pair_off = off                      # pixel-pair layout [cinp][7][8][32]
+                    off += cinp * 7 * 8 * 32
             arr[i] = capi.FvpConvOp(o["kind"], o["src"], o["dst"], o["res"], o["cin"], o["cout"], o["kh"], o["kw"],
-                                    o["h"], o["w"], o["flags"], w_off, e_off, cinp, coutp, wino_off)
+                                    o["h"], o["w"], o["flags"], w_off, e_off, cinp, coutp, wino_off, pair_off)
         self.nparams = off
         self.op_array = arr
         return self
