@@ -64,6 +64,7 @@ struct ConvArgs {
   unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
   int tpp, tpr_log2;  // Winograd: 2x2 tiles per plane band of a workgroup, log2(tiles per row)
   int wino_ni;        // Winograd: input DMA rounds (of 512 x 16 B) per chunk
+  int wrow;           // k_conv_dma: floats per packed weight row (coutp, or 2*coutp for the paired transposed conv)
   unsigned m_tpp;
 };
 
@@ -348,6 +349,59 @@ __device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x16 (&a
   }
 }
 
+// Epilogue of the paired transposed conv: blocks cb / cb + CB/2 are output columns 2x / 2x+1.
+template <int CB, int PB, bool HAS_RES>
+__device__ __forceinline__ void conv_epilogue_tpair(const ConvArgs& a, f32x16 (&acc)[CB][PB], int wave, int l31,
+                                                    int half, int plane0, int y0, int dy) {
+  constexpr int CH = CB / 2;
+  const float* bias = a.epi;
+  const float* scale = a.epi + a.coutp;
+  const float* shift = a.epi + 2 * a.coutp;
+  const bool relu = a.flags & FVP_EPI_RELU;
+  const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
+  const int tile_px = a.TN * a.TH * a.W;
+  const int OHW = a.OH * a.OW;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int q = (wave * PB + pb) * 32 + l31;
+    const int qc = q < tile_px ? q : 0;
+    const int n = fdiv(qc, a.m_thw), r2 = qc - n * (a.TH * a.W);
+    const int ty = fdiv(r2, a.m_w), tx = r2 - ty * a.W;
+    const int plane = plane0 + n, y = y0 + ty;
+    const bool pix_ok = q < tile_px && plane < a.planes && y < a.H;
+    const unsigned pix = pix_ok ? unsigned((2 * y + dy) * a.OW + 2 * tx) : 0u;
+    const unsigned pbase = pix_ok ? unsigned(plane) * a.cout : 0u;
+#pragma unroll
+    for (int cb = 0; cb < CH; ++cb) {
+      float2 rv[16];
+      unsigned o[16];
+      bool ok[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        ok[r] = pix_ok && co < a.cout;
+        o[r] = (pbase + (ok[r] ? co : 0)) * unsigned(OHW) + pix;
+        if (HAS_RES) rv[r] = *reinterpret_cast<const float2*>(a.res + o[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // < coutp: epi vectors are padded
+        float v[2] = {acc[cb][pb][r], acc[cb + CH][pb][r]};
+        const float rr[2] = {HAS_RES ? rv[r].x : 0.f, HAS_RES ? rv[r].y : 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float x = bn_affine(v[e], bias[co], scale[co], shift[co]);
+          if (HAS_RES && !res_after) x += rr[e];
+          if (relu) x = fmaxf(x, 0.0f);
+          if (HAS_RES && res_after) x += rr[e];
+          v[e] = x;
+        }
+        if (ok[r]) *reinterpret_cast<float2*>(a.dst + o[r]) = make_float2(v[0], v[1]);
+      }
+    }
+  }
+}
+
 // Wide epilogue for stride-1 outputs of the pipelined kernel: each 32x32 accumulator tile goes
 // through a 4 KB per-wave LDS scratch so that a lane ends up with 4 consecutive pixels of one
 // channel -> dwordx4 residual loads and dwordx4 stores in 128-byte runs (the MFMA layout gives a
@@ -427,7 +481,13 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&a
 // tap to the right, and a tile column is a pixel PAIR: row co computes pixel 2j, row 16+co pixel
 // 2j+1, over KW+1 taps (the extra tap of each row set has a zero weight, which leaves the fma
 // chain bit-identical).  7/8 of the MFMA work is useful instead of 1/2.
-template <int KH, int KW, int CB, int PB, bool PAIR = false>
+//
+// TPAIR (ConvTranspose k2 s2, 2-D): blockIdx.z = output row parity dy; the weight rows of the two
+// column taps are concatenated ([dy][cinp][dx*coutp + co]), so accumulator block cb and
+// cb + CB/2 of a lane are output pixels (2x, 2x+1) of the same cout: the input tile is read once
+// for both taps and the outputs leave as float2 (the tap-per-launch form reads it four times and
+// stores single floats at stride 2).
+template <int KH, int KW, int CB, int PB, bool PAIR = false, bool TPAIR = false>
 __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
   constexpr int KT = PAIR ? KW + 1 : KW;             // taps per kernel row in the packed layout
@@ -449,7 +509,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   const int co0 = blockIdx.y * CBW;
   if (a.plane_valid && a.TN == 1 && !a.plane_valid[plane0 / a.valid_div]) return;
   const int tapT = blockIdx.z;
-  const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.coutp + co0;
+  const float* wts = a.wts + size_t(tapT) * a.cinp * KK * a.wrow + co0;
 
   const int Wq = PAIR ? W >> 1 : W;                  // tile columns per image row (pixels or pixel pairs)
   const int tile_px = a.TN * a.TH * Wq;
@@ -514,12 +574,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
       }
     }
     const int avail_rows = (a.cinp - c0) * KK;
-    const float* gw = wts + size_t(c0) * KK * a.coutp;
+    const float* gw = wts + size_t(c0) * KK * a.wrow;
     for (int g = wave; g * 64 < nwq; g += 4) {
       const int it = g * 64 + lane;
       if (it < nwq) {
         const int row = it / (CBW / 4), q = it - row * (CBW / 4);
-        const float* src = row < avail_rows ? gw + size_t(row) * a.coutp + 4 * q : a.zeros;
+        const float* src = row < avail_rows ? gw + size_t(row) * a.wrow + 4 * q : a.zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(ws + g * 256), 16, 0, 0);
       }
@@ -594,6 +654,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
       conv_epilogue_pair<PB, true>(a, acc[0], wave, l31, half, plane0, y0);
     else
       conv_epilogue_pair<PB, false>(a, acc[0], wave, l31, half, plane0, y0);
+  } else if (TPAIR) {
+    if (a.flags & FVP_EPI_RES)
+      conv_epilogue_tpair<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, tapT);
+    else
+      conv_epilogue_tpair<CB, PB, false>(a, acc, wave, l31, half, plane0, y0, tapT);
   } else if (a.ntapT > 1 || (a.ablate & 16)) {          // transposed conv: strided outputs, scalar stores
     if (a.flags & FVP_EPI_RES)
       conv_epilogue<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
@@ -682,6 +747,19 @@ k_pack_pair(const float* __restrict__ w, int cin, int cout, int cinp, int kh, in
   float v = 0.0f;
   if (co < cout && ci < cin && sx >= 0 && sx < kw) v = w[((size_t(co) * cin + ci) * kh + ky) * kw + sx];
   dst[i] = v;
+}
+
+// Paired layout of ConvTranspose(k2,s2) weights [cin][cout][2][2]: [dy][cinp][dx*coutp + co].
+__global__ void __launch_bounds__(256)
+k_pack_tpair(const float* __restrict__ w, int cin, int cout, int cinp, int coutp, float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * cinp * 2 * coutp) return;
+  const int co = i % coutp;
+  int r = i / coutp;
+  const int dx = r & 1;
+  r >>= 1;
+  const int ci = r % cinp, dy = r / cinp;
+  dst[i] = (co < cout && ci < cin) ? w[((size_t(ci) * cout + co) * 2 + dy) * 2 + dx] : 0.0f;
 }
 
 template <int KH, int KW, int CB, int PB>
@@ -811,6 +889,53 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s) : launch_wino<2, 4>(a, grid, lds, s);
 }
 
+// ConvTranspose(k2,s2) in the paired form: CB = 2*coutp/32 accumulator blocks (both column taps),
+// grid.z = output row parity.
+static int plan_and_launch_tpair(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
+  const int CB = 2 * op.coutp / 32, PB = 4 / CB;         // (2,2) or (4,1)
+  a.wts = params + op.pair_off;
+  a.wrow = 2 * op.coutp;
+  a.ntapT = 2;
+  a.tapT_w = 1;
+  a.ablate = kAblate;
+  const int hw = op.h * op.w, TP = PB * 128;
+  a.TW = op.w;
+  if (hw <= TP) {
+    a.TH = op.h;
+    a.TN = TP / hw;
+  } else if (op.w <= TP) {
+    a.TH = TP / op.w;
+    a.TN = 1;
+  } else {
+    return FVP_ELIMIT;
+  }
+  a.m_w = make_magic(a.TW);
+  a.m_thw = make_magic(a.TH * a.TW);
+  a.tiles_x = 1;
+  a.tiles_y = ceil_div(op.h, a.TH);
+  a.vec = a.dma = 1;
+  a.zeros = params;
+  const size_t per_ch = (size_t(a.TN) * a.TH * (a.TW + 4) + size_t(32) * CB) * sizeof(float);
+  int CC = int((kLdsBudget - 64) / (per_ch * 2)) & ~1;
+  if (CC > op.cinp) CC = op.cinp;
+  if (CC < 2) return FVP_ELIMIT;
+  while (CC > 2 && size_t(CC) * a.TN * a.TH * (a.TW / 4 + 1) + 1 > 2048) CC -= 2;
+  for (int d = CC; d >= 2 && d * 2 > CC; d -= 2)
+    if (op.cinp % d == 0) { CC = d; break; }
+  a.CC = CC;
+  a.m_qpr = make_magic(a.TW / 4 + 1);
+  a.m_rpc = make_magic(a.TN * a.TH);
+  a.m_thp = make_magic(a.TH);
+  const size_t lds = std::max<size_t>(16 + 2 * (per_ch * CC + 16), 16 + 16384);
+  dim3 grid(a.tiles_y * ceil_div(planes, a.TN), 1, 2);
+  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * 4.0 * hw * planes, 1, prof_level() >= 2);
+  if (CB == 2)
+    hipLaunchKernelGGL((k_conv_dma<1, 1, 2, 2, false, true>), grid, dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((k_conv_dma<1, 1, 4, 1, false, true>), grid, dim3(256), lds, s, a);
+  return launch_status();
+}
+
 // Tile selection: all couts per workgroup (CB = coutp/32), PB so that CB*PB <= 8 accumulator
 // tiles per wave, the tile shaped to cover full image rows where possible.
 static int plan_and_launch(const FvpConvOp& op, const float* params, float* const* bufs, int planes,
@@ -846,6 +971,9 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   a.OH = op.h * a.osy;
   a.OW = op.w * a.osx;
   if (double(planes) * std::max(op.cin, op.cout) * a.OH * a.OW >= 2147483648.0) return FVP_ELIMIT;
+  a.wrow = op.coutp;
+  if (tr && op.h > 1 && op.pair_off > 0 && !kNoPair && op.w % 4 == 0 && (op.coutp == 32 || op.coutp == 64))
+    return plan_and_launch_tpair(op, a, params, planes, s);
   const int CBfull = op.coutp / 32;
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
   a.ablate = kAblate;
@@ -978,8 +1106,12 @@ extern "C" int fvp_pack_conv(const float* weight, const float* bias, const float
   hipLaunchKernelGGL(k_pack_conv, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(s), weight, bias, bn_gamma,
                      bn_beta, bn_mean, bn_var, eps, transposed, op->cin, op->cout, op->cinp, op->coutp, op->kh,
                      op->kw, params + op->w_off, params + op->e_off);
-  if (op->pair_off > 0) {
-    FVP_REQUIRE(!transposed && op->cout <= 16 && op->coutp == 32);
+  if (op->pair_off > 0 && transposed) {
+    FVP_REQUIRE(op->kh == 2 && op->kw == 2);
+    hipLaunchKernelGGL(k_pack_tpair, dim3(ceil_div(4 * op->cinp * op->coutp, 256)), dim3(256), 0, as_stream(s), weight,
+                       op->cin, op->cout, op->cinp, op->coutp, params + op->pair_off);
+  } else if (op->pair_off > 0) {
+    FVP_REQUIRE(op->cout <= 16 && op->coutp == 32);
     hipLaunchKernelGGL(k_pack_pair, dim3(ceil_div(op->cinp * op->kh * (op->kw + 1) * 32, 256)), dim3(256), 0,
                        as_stream(s), weight, op->cin, op->cout, op->cinp, op->kh, op->kw, params + op->pair_off);
   }

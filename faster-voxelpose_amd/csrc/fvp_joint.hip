@@ -22,6 +22,8 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int o) {
   return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // wn layout: conv_w[F][9] | conv_b[F] | bn_scale[F] | bn_shift[F] | fc1_w[Hd][F] | fc1_b[Hd] | fc2_w[Hd] | fc2_b
 __global__ void __launch_bounds__(256)
 k_softargmax_weightnet(const float* __restrict__ feat, const float* __restrict__ center_grid,
@@ -102,26 +104,32 @@ k_softargmax_weightnet(const float* __restrict__ feat, const float* __restrict__
         const int yy = 2 * wy - 1 + r, xx = 2 * wx - 1 + c;
         patch[r][c] = (yy >= 0 && yy < C && xx >= 0 && xx < C) ? map[yy * C + xx] : 0.0f;
       }
+    // the two outputs of a window row (ox = 0, 1) run as one packed fma chain: same fmaf per
+    // element, half the VALU instructions
+    f32x2 pp[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pp[r][c] = f32x2{patch[r][c], patch[r][c + 1]};
 #pragma unroll
     for (int f = 0; f < kMaxF; ++f) {
       if (f < F) {
         float k[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) k[q] = cw[f * 9 + q];
-        float best = -INFINITY;
+        f32x2 best = f32x2{-INFINITY, -INFINITY};
 #pragma unroll
-        for (int oy = 0; oy < 2; ++oy)
+        for (int oy = 0; oy < 2; ++oy) {
+          f32x2 a = f32x2{0.0f, 0.0f};
 #pragma unroll
-          for (int ox = 0; ox < 2; ++ox) {
-            float a = 0.0f;
+          for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-              for (int kx = 0; kx < 3; ++kx) a = fmaf(patch[oy + ky][ox + kx], k[ky * 3 + kx], a);
-            a = (a + cb[f]) * bs[f] + bh[f];
-            best = fmaxf(best, a);
-          }
-        sum[f] += fmaxf(best, 0.0f);
+            for (int kx = 0; kx < 3; ++kx)
+              a = __builtin_elementwise_fma(pp[oy + ky][kx], f32x2{k[ky * 3 + kx], k[ky * 3 + kx]}, a);
+          a = (a + cb[f]) * bs[f] + bh[f];
+          best = __builtin_elementwise_max(best, a);
+        }
+        sum[f] += fmaxf(fmaxf(best.x, best.y), 0.0f);
       }
     }
   }

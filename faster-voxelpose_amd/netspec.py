@@ -205,6 +205,9 @@ class StackSpec:
                         and o["w"] % 4 == 0):
                     pair_off = off                      # pixel-pair layout [cinp][7][8][32]
                     off += cinp * 7 * 8 * 32
+                if (o["kind"] == capi.OP_CONVT2 and o["h"] > 1 and o["w"] % 4 == 0 and coutp in (32, 64)):
+                    pair_off = off                      # column-tap pairs [dy][cinp][dx*coutp + co]
+                    off += 4 * cinp * coutp
             arr[i] = capi.FvpConvOp(o["kind"], o["src"], o["dst"], o["res"], o["cin"], o["cout"], o["kh"], o["kw"],
                                     o["h"], o["w"], o["flags"], w_off, e_off, cinp, coutp, wino_off, pair_off)
         self.nparams = off

@@ -147,8 +147,9 @@ typedef struct FvpConvOp {
   int32_t wino_off;           /* 0, or float offset of the Winograd-domain copy of a 3x3    */
                               /* conv's weights ([cinp][coutp][16]); when set the conv runs  */
                               /* as F(2x2,3x3) (requires even H, W a power of two)           */
-  int32_t pair_off;           /* 0, or float offset of the pixel-pair copy of a 7x7 conv's   */
-                              /* weights with cout <= 16 ([cinp][7][8][32], see fvp_conv.hip) */
+  int32_t pair_off;           /* 0, or float offset of the pixel-pair copy of the weights:    */
+                              /* 7x7 conv with cout <= 16 -> [cinp][7][8][32]; 2-D            */
+                              /* ConvTranspose(k2,s2) -> [dy][cinp][dx*coutp+co] (fvp_conv.hip) */
 } FvpConvOp;
 
 /* bufs[i] = device pointer of activation buffer i (caller sized: planes*C*H*W floats).
