@@ -16,6 +16,7 @@ from .joint_localization_net import JointLocalizationNet
 class FasterVoxelPoseNet(nn.Module):
     def __init__(self, cfg, _lib=None):
         super().__init__()
+        self.cfg = cfg
         self.max_people = cfg.CAPTURE_SPEC.MAX_PEOPLE
         self.num_joints = cfg.DATASET.NUM_JOINTS
         self.device = torch.device(cfg.DEVICE)
@@ -71,6 +72,45 @@ class GraphedForward:
             self.static_in.copy_(input_heatmaps, non_blocking=True)
         self.graph.replay()
         return self.out
+
+
+class PipelinedForward:
+    """Several batches in flight on one GPU: batch i runs on HIP stream i % depth with its own
+    replica of the model (same weights, private scratch buffers).  The detection stage of a batch
+    (CenterNet / C2CNet / NMS: small, latency-bound launches) then fills the gaps and tails of the
+    previous batch's joint stage (P2PNet: large, matrix-core-bound launches); the forward has no
+    host synchronisation, so submitting is just enqueueing.
+
+    ``submit`` returns ``(outputs, event)``; the outputs are valid for a consumer stream after
+    ``event.wait()`` (or after ``synchronize()``).  Results are identical to the plain forward:
+    every kernel is deterministic and replicas share nothing but read-only inputs."""
+
+    def __init__(self, model, depth=2):
+        assert depth >= 1
+        self.models = [model]
+        self.streams = [torch.cuda.Stream(device=model.device) for _ in range(depth)]
+        for _ in range(1, depth):
+            m = FasterVoxelPoseNet(model.cfg).to(model.device)
+            m.load_state_dict(model.state_dict())
+            m.eval()
+            self.models.append(m)
+        self.depth = depth
+        self._i = 0
+
+    def submit(self, **forward_kwargs):
+        k = self._i % self.depth
+        self._i += 1
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream())      # inputs produced on the caller's stream
+        with torch.cuda.stream(st), torch.no_grad():
+            out = self.models[k](**forward_kwargs)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return out, ev
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
 
 
 def get(cfg):

@@ -198,3 +198,29 @@ def test_fused_c2c_equals_generic_gpu():
     generic = model.pose_net.c2c_net(z)
     model.engine.fused_c2c = True
     assert torch.equal(fused, generic)
+
+
+@pytest.mark.gpu
+def test_pipelined_forward_equals_plain_forward():
+    """Three batches in flight on three streams (FV.PipelinedForward) give bit-identical results to
+    the plain forward, batch by batch."""
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = S.make_cfg("panoptic", device="cuda:0", min_score=-1.0)
+    cams, seq = S.load_cameras("panoptic")
+    rt = S.resize_transform(cfg).to("cuda:0")
+    model = FV.get(cfg).to("cuda:0")
+    model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=11))
+    heats = [S.heatmaps_blobs(cfg, cams, seq, 2, people=3, seed=40 + i).to("cuda:0") for i in range(5)]
+    meta = {"seq": [seq] * 2}
+    with torch.no_grad():
+        want = []
+        for h in heats:
+            f, p, c, _, _ = model(meta=meta, input_heatmaps=h, cameras=cams, resize_transform=rt)
+            want.append((f.clone(), p.clone(), c.clone()))
+        torch.cuda.synchronize()
+        pipe = FV.PipelinedForward(model, depth=3)
+        got = [pipe.submit(meta=meta, input_heatmaps=h, cameras=cams, resize_transform=rt) for h in heats]
+        pipe.synchronize()
+    for (f, p, c), ((gf, gp, gc, _, _), ev) in zip(want, got):
+        assert ev.query()
+        assert torch.equal(f, gf) and torch.equal(p, gp) and torch.equal(c, gc)
