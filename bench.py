@@ -156,7 +156,7 @@ def main():
         # the event pairs cost ~2 % and would serialise nothing but still perturb the timed region
         if not args.no_prof and graphed is None:
             lib.fvp_prof_reset()
-            lib.fvp_prof_enable(1)
+            lib.fvp_prof_enable(2)                # one event pair per launch, every class
             for _ in range(max(1, args.prof_steps)):
                 step(0, pipelined=False)
             torch.cuda.synchronize()
@@ -171,7 +171,8 @@ def main():
 
     if rank == 0:
         names = {capi.K_PROJECT_WHOLE: "project_whole", capi.K_PROJECT_TRIPLANE: "project_triplane",
-                 capi.K_CONV: "conv_mfma", capi.K_SOFTARGMAX: "softargmax_weightnet", capi.K_OTHER: "other"}
+                 capi.K_CONV: "conv_other", capi.K_CONV_WINO: "conv_winograd_3x3",
+                 capi.K_SOFTARGMAX: "softargmax_weightnet", capi.K_OTHER: "other"}
         kern = {}
         if not args.no_prof:
             for cls, nm in names.items():
@@ -183,34 +184,52 @@ def main():
         Cn = cfg.INDIVIDUAL_SPEC.VOXELS_PER_AXIS[0]
         roof = None
         if kern:
-            conv, proj = kern["conv_mfma"], kern["project_triplane"]
-            conv_tf = conv["flops"] / (conv["ms_total"] * 1e-3) / 1e12 if conv["ms_total"] > 0 else 0.0
+            wino, conv, proj = kern["conv_winograd_3x3"], kern["conv_other"], kern["project_triplane"]
+
+            def tf(k):
+                return k["flops"] / (k["ms_total"] * 1e-3) / 1e12 if k["ms_total"] > 0 else 0.0
+
             pbytes = algorithmic_bytes_projection(V, J, H, W, Cn, valid_people) * B * prof_steps
             proj_gbs = pbytes / (proj["ms_total"] * 1e-3) / 1e9 if proj["ms_total"] > 0 else 0.0
-            # dominant kernel by accumulated time decides which roofline is the headline
-            if conv["ms_total"] >= proj["ms_total"]:
-                roof = {"kernel": "k_conv_dma / k_conv (fp32 MFMA implicit GEMM): every conv launch of CenterNet, "
-                                  "C2CNet and P2PNet, timed per stack run", "bound": "mfma",
-                        "achieved": conv_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": conv_tf / MFMA_F32_PEAK_TF, "traffic": None,
-                        "avg_launch_us": 1e3 * conv["ms_total"] / max(conv["launches"], 1)}
-            else:
+            # headline roofline = the kernel with the largest accumulated time.  FLOPs are the
+            # ALGORITHMIC ones (direct-conv 2*MAC); the Winograd kernel executes
+            # 16/36 of them on the matrix cores.
+            cands = {"k_conv_wino": wino["ms_total"], "k_conv_dma": conv["ms_total"],
+                     "k_project_triplane": proj["ms_total"]}
+            top = max(cands, key=cands.get)
+            if top == "k_project_triplane":
                 roof = {"kernel": "k_project_triplane", "bound": "hbm", "achieved": proj_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": proj_gbs / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": 1e3 * proj["ms_total"] / max(proj["launches"], 1)}
-            # HBM-side traffic of the dominant kernel class from the committed rocprofv3 PMC passes
-            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, mean per conv launch), if present
+            else:
+                k = wino if top == "k_conv_wino" else conv
+                roof = {"kernel": ("k_conv_wino (3x3 convs as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32; P2PNet "
+                                   "res-blocks)" if top == "k_conv_wino" else
+                                   "k_conv_dma (fp32 MFMA implicit GEMM: 7x7, 1x1, transposed and small-map 3x3 convs)"),
+                        "bound": "mfma", "achieved": tf(k), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": tf(k) / MFMA_F32_PEAK_TF, "traffic": None,
+                        "avg_launch_us": 1e3 * k["ms_total"] / max(k["launches"], 1),
+                        "flops": "algorithmic (direct conv 2*MAC); executed MFMA flops = 4/9 of that"
+                                 if top == "k_conv_wino" else "algorithmic = executed"}
+            # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes
+            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, mean per launch), if present
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if os.path.isfile(pmc):
                 try:
                     with open(pmc) as f:
                         t = json.load(f)
-                    roof["traffic"] = t.get("conv_mfma_bytes_per_launch" if roof["bound"] == "mfma"
-                                            else "project_triplane_bytes_per_launch")
+                    key = {"k_conv_wino": "conv_wino_bytes_per_launch", "k_conv_dma": "conv_dma_bytes_per_launch",
+                           "k_project_triplane": "project_triplane_bytes_per_launch"}[top]
+                    roof["traffic"] = t.get(key)
                     roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
                 except Exception:
                     pass
-            kern["conv_mfma"]["tflops"] = conv_tf
+            wino["tflops_algorithmic"] = tf(wino)
+            conv["tflops"] = tf(conv)
+            allconv = {"ms_total": wino["ms_total"] + conv["ms_total"], "launches": wino["launches"] + conv["launches"],
+                       "flops": wino["flops"] + conv["flops"]}
+            allconv["tflops_algorithmic"] = tf(allconv)
+            kern["conv_all"] = allconv
             kern["project_triplane"]["algorithmic_GBps"] = proj_gbs
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

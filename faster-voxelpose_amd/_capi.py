@@ -17,7 +17,7 @@ FVP_MAX_JOINTS = 32
 
 OP_CONV, OP_POOL2, OP_CONVT2 = 0, 1, 2
 EPI_RELU, EPI_RES, EPI_RES_AFTER_RELU = 1, 2, 4
-K_PROJECT_WHOLE, K_PROJECT_TRIPLANE, K_CONV, K_SOFTARGMAX, K_OTHER, K_COUNT = 0, 1, 2, 3, 4, 5
+K_PROJECT_WHOLE, K_PROJECT_TRIPLANE, K_CONV, K_SOFTARGMAX, K_OTHER, K_CONV_WINO, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 
 
 class FvpGeom(C.Structure):

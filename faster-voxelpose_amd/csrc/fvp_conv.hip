@@ -885,7 +885,7 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   a.m_thp = make_magic(a.TH + 2);
   const size_t lds = 16 + 3 * slot;
   dim3 grid(a.tiles_y * ceil_div(planes, TN), op.coutp / CBW, 1);
-  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
+  ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s) : launch_wino<2, 4>(a, grid, lds, s);
 }
 

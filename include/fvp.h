@@ -224,11 +224,12 @@ int fvp_fuse_poses(const float* pose2d, const float* pmax, const float* wgt, con
  * fvp_prof_enable(1): kernel classes are bracketed by hipEvents on the stream they are launched
  * on -- per launch for the projection / soft-argmax / small kernels, one pair per
  * fvp_conv_stack_run for the conv class (launches = convs in the stack), so that a ~100-launch
- * step is not perturbed.  fvp_prof_enable(2): additionally one pair per conv launch (diagnostics).
+ * step is not perturbed.  fvp_prof_enable(2): one pair per conv LAUNCH instead, the Winograd 3x3
+ * launches (the dominant kernel) in their own class FVP_K_CONV_WINO, all others in FVP_K_CONV.
  * fvp_prof_read synchronises the events and returns accumulated milliseconds, launch count and
  * algorithmic FLOPs since the last reset. */
 enum { FVP_K_PROJECT_WHOLE = 0, FVP_K_PROJECT_TRIPLANE = 1, FVP_K_CONV = 2, FVP_K_SOFTARGMAX = 3,
-       FVP_K_OTHER = 4, FVP_K_COUNT = 5 };
+       FVP_K_OTHER = 4, FVP_K_CONV_WINO = 5, FVP_K_COUNT = 6 };
 int fvp_prof_enable(int on);
 int fvp_prof_read(int cls, double* ms, int64_t* launches, double* flops);
 int fvp_prof_reset(void);

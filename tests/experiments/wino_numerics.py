@@ -1,9 +1,9 @@
-"""Scratch experiment: does a Winograd F(2x2,3x3) fp32 evaluation of the 3x3 convs stay inside the
+"""Experiment (test infrastructure, not collected by pytest): does a Winograd F(2x2,3x3) fp32 evaluation of the 3x3 convs stay inside the
 parity criteria of tests/common.py?  Patches the ORACLE's conv (test infrastructure) only."""
 import sys, os
 import numpy as np, torch
 import torch.nn.functional as F
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R, os.path.join(R, "oracle"), os.path.join(R, "tests"), os.path.join(R, "tests", "golden")]
 import fvp_oracle as O
 from cases import CASES, make_inputs

@@ -1,2 +1,3 @@
-bash tools/gpu_check.sh r01f
-bash tools/gpu_pmc.sh r01f
+tag="${1:-r01g}"
+bash tools/gpu_check.sh $tag
+bash tools/gpu_pmc.sh $tag

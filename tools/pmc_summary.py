@@ -38,20 +38,22 @@ for n in rows:
 
 # machine-readable traffic summary for bench.py's roofline.traffic
 import json
-conv_f = conv_w = conv_n = 0.0
 out = {}
+grp = {"conv_wino": [0.0, 0.0, 0.0], "conv_dma": [0.0, 0.0, 0.0]}
 for n in rows:
     c = {k: sum(v) / len(v) for k, v in acc[n].items()}
     nl = len(acc[n].get("FETCH_SIZE", []))
-    if "k_conv" in n and nl:
-        conv_f += c.get("FETCH_SIZE", 0.0) * nl
-        conv_w += c.get("WRITE_SIZE", 0.0) * len(acc[n].get("WRITE_SIZE", []))
-        conv_n += nl
+    g = "conv_wino" if "k_conv_wino" in n else ("conv_dma" if "k_conv" in n else None)
+    if g and nl:
+        grp[g][0] += c.get("FETCH_SIZE", 0.0) * nl
+        grp[g][1] += c.get("WRITE_SIZE", 0.0) * len(acc[n].get("WRITE_SIZE", []))
+        grp[g][2] += nl
     if "k_project_triplane" in n and nl:
         out["project_triplane_bytes_per_launch"] = (2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024
-if conv_n:
-    out["conv_mfma_bytes_per_launch"] = (2 * conv_f + conv_w) * 1024 / conv_n
-    out["conv_launches_sampled"] = conv_n
+for g, (f, w, n) in grp.items():
+    if n:
+        out[g + "_bytes_per_launch"] = (2 * f + w) * 1024 / n
+        out[g + "_launches_sampled"] = n
 out["note"] = "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)"
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
