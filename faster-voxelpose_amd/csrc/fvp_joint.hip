@@ -242,10 +242,19 @@ extern "C" int fvp_softargmax_weightnet(const float* feat, const float* center_g
                                         int nP, int J, int C, int F, int Hd, const uint8_t* person_valid,
                                         float* pose2d, float* pmax, float* wgt, fvp_stream_t s) {
   FVP_REQUIRE(feat && center_grid && wn && pose2d && pmax && wgt && nP >= 0 && J > 0);
-  FVP_LIMIT(F >= 1 && F <= kMaxF && Hd >= 1 && Hd <= 1024 && C >= 2 && C % 2 == 0 && C <= 120);
+  FVP_LIMIT(F >= 1 && F <= kMaxF && Hd >= 1 && Hd <= 1024 && C >= 2 && C % 2 == 0 && C <= 192);
   if (nP == 0) return 0;
   const size_t lds = (size_t((C * C + 1) & ~1)) * 4 + 12 * 8 + (5 * kMaxF + Hd) * 4;
-  FVP_LIMIT(lds <= 64 * 1024);
+  FVP_LIMIT(lds <= 160 * 1024);
+  if (lds > 64 * 1024) {                               // jln128: the 64 KB map needs the large-LDS opt-in
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softargmax_weightnet),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return int(e);
+      attr = true;
+    }
+  }
   // algorithmic FLOPs of WeightNet's conv (2*9*F per pixel) + MLP, for the profile hook
   ProfScope ps(FVP_K_SOFTARGMAX, as_stream(s), double(nP) * 3 * J * (2.0 * 9 * F * C * C + 2.0 * F * Hd + 2.0 * Hd));
   hipLaunchKernelGGL(k_softargmax_weightnet, dim3(J, 3, nP), dim3(256), lds, as_stream(s), feat, center_grid, wn,

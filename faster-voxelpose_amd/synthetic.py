@@ -35,6 +35,11 @@ SHAPES = {
                    space=[12000.0, 12000.0, 2000.0], center=[3000.0, 4500.0, 1000.0],
                    voxels=[80, 80, 20], N=5, min_score=0.1,
                    calib="calibration_campus.json", seq="campus"),
+    # BASELINE.json configs[3]: the Panoptic cameras with a 128x128x32 detection grid and jln128
+    "panoptic128": dict(V=5, J=15, hm=[240, 128], img=[960, 512], ori=[1920, 1080],
+                        space=[8000.0, 8000.0, 2000.0], center=[0.0, -500.0, 800.0],
+                        voxels=[128, 128, 32], N=10, min_score=0.3, cube=[128, 128, 128],
+                        calib="calibration_panoptic_demo.json", seq="customized_sequence"),
     # not a reference config: a miniature (Campus cameras) for fast kernel-logic tests
     "tiny": dict(V=3, J=5, hm=[50, 40], img=[200, 160], ori=[360, 288],
                  space=[12000.0, 12000.0, 2000.0], center=[3000.0, 4500.0, 1000.0],
@@ -68,7 +73,7 @@ def load_cameras(name):
     s = SHAPES[name]
     with open(os.path.join(_FIXTURES, s["calib"])) as f:
         raw = json.load(f)
-    if name == "panoptic":
+    if name.startswith("panoptic"):
         return {s["seq"]: raw[s["seq"]]}, s["seq"]
     if name == "tiny":
         return {s["seq"]: [raw[k] for k in sorted(raw)]}, s["seq"]

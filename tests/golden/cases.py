@@ -19,6 +19,8 @@ CASES = {
     "panoptic_g_b2_thr": ("panoptic", "g", 2, 3, 5, 7, 17.9),
     "panoptic_u_b1_all": ("panoptic", "u", 1, 0, 2, 7, -1.0),
     "shelf_g_b1_all": ("shelf", "g", 1, 4, 3, 11, -1.0),
+    # BASELINE.json configs[3] shape: 128x128x32 detection grid, jln128
+    "panoptic128_g_b1_all": ("panoptic128", "g", 1, 4, 10, 7, -1.0),
 }
 
 
