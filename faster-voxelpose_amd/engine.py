@@ -306,6 +306,34 @@ class HotPath:
                    _ptr(offset), self.stream())
         return boxes, offset
 
+    def softargmax_weightnet(self, joint_features, grids=None):
+        """Standalone launch of the fused soft-argmax + WeightNet kernel on features in the
+        reference's layout [3, P, J, C, C] (joint_localization_net.py:20-34, weight_net.py:69-80).
+        Returns pose [3,P,J,2], confs [P], weights [3P,J,1]."""
+        x = joint_features
+        self._check_tensor(x, "joint_features")
+        assert x.dim() == 5 and x.shape[0] == 3 and x.shape[2] == self.J and x.shape[3] == x.shape[4] == self.C
+        P, J, Cn = x.shape[1], self.J, self.C
+        s = self.stream()
+        feat = x.permute(1, 0, 2, 3, 4).contiguous()                # kernel layout [P][3][J][C*C] (a copy, no arithmetic)
+        grid = self.center_grid if grids is None else grids.reshape(3, Cn * Cn, 2).contiguous()
+        pose2d = torch.empty((P, 3, J, 2), device=self.device)
+        pmax = torch.empty((P, 3, J), device=self.device)
+        wgt = torch.empty((P, 3, J), device=self.device)
+        if P == 0:
+            return pose2d.permute(1, 0, 2, 3), torch.empty((0,), device=self.device), wgt.reshape(0, J, 1)
+        self._call("fvp_softargmax_weightnet", _ptr(feat), _ptr(grid), _ptr(self.wn_params), self.beta, P, J, Cn,
+                   self.F, self.Hd, None, _ptr(pose2d), _ptr(pmax), _ptr(wgt), s)
+        # confs = mean over (plane, joint) of the softmax maxima: the fusion kernel computes it
+        centers = torch.zeros((P, 7), device=self.device)
+        offset = torch.zeros((P, 3), device=self.device)
+        fused5 = torch.empty((P, J, 5), device=self.device)
+        planes = torch.empty((3, P, J, 2), device=self.device)
+        self._call("fvp_fuse_poses", _ptr(pose2d), _ptr(pmax), _ptr(wgt), _ptr(offset), None, P, J, _ptr(centers),
+                   _ptr(fused5), _ptr(planes), s)
+        return pose2d.permute(1, 0, 2, 3).contiguous(), centers[:, 4].clone(), \
+            wgt.permute(1, 0, 2).reshape(3 * P, J, 1).contiguous()
+
     def jln(self, meta, heatmaps, proposal_centers, mask, cameras, resize_transform, fused=True,
             reuse_staging=False):
         """JointLocalizationNet.forward (joint_localization_net.py:64-99) for all B*N proposal

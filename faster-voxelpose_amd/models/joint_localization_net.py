@@ -17,11 +17,24 @@ from .weight_net import WeightNet
 
 
 class SoftArgmaxLayer(nn.Module):
-    """Holds beta (:15-18); the expectation runs in ``fvp_softargmax_weightnet``."""
+    """Holds beta (:15-18); the expectation runs in ``fvp_softargmax_weightnet`` -- fused inside
+    ``JointLocalizationNet.forward``, or standalone through ``forward(x, grids)`` (:20-34)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, _engine=None, _weight_net=None):
         super().__init__()
         self.beta = cfg.NETWORK.BETA
+        self._engine = [_engine]              # in a list: not a sub-module, not in the state_dict
+        self._weight_net = [_weight_net]
+
+    def forward(self, x, grids):
+        """x [3,P,J,C,C], grids [3,C*C,2] -> (pose [3,P,J,2], confs [P])."""
+        eng = self._engine[0]
+        if eng is None:
+            raise RuntimeError("SoftArgmaxLayer needs the engine of its JointLocalizationNet for a standalone launch")
+        if self._weight_net[0] is not None:
+            self._weight_net[0].ensure_packed()
+        pose, confs, _ = eng.softargmax_weightnet(x, grids)
+        return pose, confs
 
 
 class JointLocalizationNet(nn.Module):
@@ -31,7 +44,7 @@ class JointLocalizationNet(nn.Module):
         self.conv_net = P2PNet(cfg.DATASET.NUM_JOINTS, cfg.DATASET.NUM_JOINTS, _engine=self.engine)
         self.weight_net = WeightNet(cfg, _engine=self.engine)
         self.project_layer = ProjectLayer(cfg, _engine=self.engine)
-        self.soft_argmax_layer = SoftArgmaxLayer(cfg)
+        self.soft_argmax_layer = SoftArgmaxLayer(cfg, _engine=self.engine, _weight_net=self.weight_net)
         self.fused_projection = True      # False: materialise cubes (fvp_project_individual + fvp_triplane_max)
 
     def forward(self, meta, heatmaps, proposal_centers, mask, cameras, resize_transform, _reuse_staging=False):

@@ -1,7 +1,8 @@
 """WeightNet -- parameter holder with the reference's ``state_dict`` keys
 (``lib/models/weight_net.py:48-67``).  Its arithmetic (conv 1->F k3, BN, max-pool, ReLU,
 global average, MLP, sigmoid; :69-80) runs fused with the soft-argmax in the HIP kernel
-``fvp_softargmax_weightnet``, launched by ``JointLocalizationNet.forward``."""
+``fvp_softargmax_weightnet``, launched by ``JointLocalizationNet.forward`` (or standalone by
+``WeightNet.forward``)."""
 import torch
 
 from ._netmodule import PackedNet
@@ -32,5 +33,7 @@ class WeightNet(PackedNet):
         self.engine.pack_weightnet(self)
 
     def forward(self, x):
-        raise NotImplementedError("WeightNet runs fused inside JointLocalizationNet.forward "
-                                  "(fvp_softargmax_weightnet); it has no standalone launch yet")
+        """x = joint features [3, P, J, C, C] -> fusion weights [3P, J, 1] (weight_net.py:69-80).
+        Standalone launch of the same fused kernel JointLocalizationNet.forward uses."""
+        self.ensure_packed()
+        return self.engine.softargmax_weightnet(x)[2]

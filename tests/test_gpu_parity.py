@@ -224,3 +224,28 @@ def test_pipelined_forward_equals_plain_forward():
     for (f, p, c), ((gf, gp, gc, _, _), ev) in zip(want, got):
         assert ev.query()
         assert torch.equal(f, gf) and torch.equal(p, gp) and torch.equal(c, gc)
+
+
+@pytest.mark.gpu
+def test_standalone_softargmax_and_weightnet_vs_oracle():
+    """SoftArgmaxLayer.forward / WeightNet.forward as standalone launches (reference layout
+    [3,P,J,C,C]) against the oracle's restatement of joint_localization_net.py:20-34 and
+    weight_net.py:69-80."""
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = S.make_cfg("panoptic", device="cuda:0", min_score=-1.0)
+    model = FV.get(cfg).to("cuda:0")
+    sd = S.fill_state_dict(model.state_dict(), seed=5)
+    model.load_state_dict(sd)
+    P, J, Cn = 4, cfg.DATASET.NUM_JOINTS, cfg.INDIVIDUAL_SPEC.VOXELS_PER_AXIS[0]
+    x = torch.from_numpy(np.random.default_rng(3).random((3, P, J, Cn, Cn), dtype=np.float32) * 0.2)
+    jn = model.joint_net
+    grid = model.engine.center_grid
+    with torch.no_grad():
+        pose, confs = jn.soft_argmax_layer(x.cuda(), grid)
+        w = jn.weight_net(x.cuda())
+    want_pose, want_conf = O.soft_argmax(x, grid.cpu(), float(cfg.NETWORK.BETA))
+    want_w = O.weight_net({k: v.cpu() for k, v in sd.items()}, "joint_net.weight_net", x, Cn)
+    assert pose.shape == (3, P, J, 2) and confs.shape == (P,) and w.shape == (3 * P, J, 1)
+    np.testing.assert_allclose(pose.cpu().numpy(), want_pose.numpy(), rtol=0, atol=2e-2)     # mm
+    np.testing.assert_allclose(confs.cpu().numpy(), want_conf.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w.cpu().numpy(), want_w.numpy(), rtol=1e-4, atol=1e-6)
