@@ -15,6 +15,8 @@
 // neighbouring heatmap pixels and every store is a contiguous 256-byte row.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fvp_common.h"
 #include "fvp_geom.h"
 
@@ -293,6 +295,88 @@ __device__ __forceinline__ void sample4(const float* __restrict__ cl, int JP, in
   for (int i = 0; i < 4; ++i) acc[i] = first ? s[i] : __fadd_rn(acc[i], s[i]);
 }
 
+// Whole-space cubes + fused z-max, quad-lane form (the default): 4 lanes per voxel, lane q
+// gathers channels [16n + 4q, +4) of every tap, so the four lanes of a voxel read one contiguous
+// 64-byte run per tap (16 cache lines per wave instruction instead of 64 -- the gather is bound by
+// the texture-addresser line rate) and lane q computes the projection of view q for the quad
+// (DPP broadcast).  Same per-channel arithmetic as k_project_whole (bit-equal cubes).
+template <int NVL>
+__global__ void __launch_bounds__(1024)
+k_project_whole_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cams,
+                  const int* __restrict__ frame_set, const float* __restrict__ ax, const float* __restrict__ ay,
+                  const float* __restrict__ az, int X, int Y, int Z, FvpGeom g, float* __restrict__ cubes,
+                  float* __restrict__ zmax) {
+  __shared__ float sm[16 * NVL][256];
+  const int cpb = 256 / Z;
+  const int b = blockIdx.y;
+  const int t = threadIdx.x, q = t & 3, vl = t >> 2;           // vl = voxel inside the workgroup
+  const int cl_ = vl / Z, z = vl - cl_ * Z;
+  const int col = blockIdx.x * cpb + cl_;
+  const int ncol = X * Y;
+  const bool active = cl_ < cpb && col < ncol;
+  const int J = g.J, JP = g.JP;
+  const size_t view_stride = size_t(g.H) * g.W * JP;
+  const float* frame = heat_cl + size_t(b) * g.V * view_stride;
+  const Cam* cm = cams + size_t(frame_set[b]) * g.V;
+  float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+  if (active) {
+    const int x = col / Y, y = col - x * Y;
+    wx = ax[x];
+    wy = ay[y];
+    wz = az[z];
+  }
+  float acc[NVL][4];
+#pragma unroll
+  for (int n = 0; n < NVL; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[n][i] = 0.0f;
+  TapD mine;
+  mine.inside = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { mine.off[k] = 0; mine.w[k] = 0.0f; }
+  if (active && q < g.V) mine = make_taps(cm[q], g, wx, wy, wz);
+  auto add_view = [&](const TapD& tv, int v) {
+#pragma unroll
+    for (int n = 0; n < NVL; ++n) {
+      const int ch0 = 16 * n + 4 * q;
+      if (ch0 < JP) {
+        if (tv.inside) sample4(frame + v * view_stride, JP, ch0, tv, v == 0, acc[n]);
+        else if (v == 0) { acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f; }
+      }
+    }
+  };
+  { const TapD tv = quad_bcast<0>(mine); if (active) add_view(tv, 0); }
+  if (g.V > 1) { const TapD tv = quad_bcast<1>(mine); if (active) add_view(tv, 1); }
+  if (g.V > 2) { const TapD tv = quad_bcast<2>(mine); if (active) add_view(tv, 2); }
+  if (g.V > 3) { const TapD tv = quad_bcast<3>(mine); if (active) add_view(tv, 3); }
+  for (int v = 4; v < g.V; ++v)
+    if (active) add_view(make_taps(cm[v], g, wx, wy, wz), v);
+  const float nv = float(g.V);
+  const size_t vox = size_t(col) * Z + z;
+  const size_t nvox = size_t(ncol) * Z;
+#pragma unroll
+  for (int n = 0; n < NVL; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 16 * n + 4 * q + i;
+      const float v = clampf(__fdiv_rn(acc[n][i], nv), 0.0f, 1.0f);
+      if (zmax) sm[c][vl] = active ? v : 0.0f;
+      if (cubes && active && c < J) cubes[(size_t(b) * J + c) * nvox + vox] = v;
+    }
+  if (zmax) {
+    __syncthreads();
+    for (int item = t; item < cpb * J; item += 1024) {
+      const int c = item / cpb, k = item - c * cpb;
+      const int cc = blockIdx.x * cpb + k;
+      if (cc < ncol) {
+        float m = sm[c][k * Z];
+        for (int zz = 1; zz < Z; ++zz) m = fmaxf(m, sm[c][k * Z + zz]);
+        zmax[(size_t(b) * J + c) * ncol + cc] = m;
+      }
+    }
+  }
+}
+
 template <int NVL>   // channel quads per lane: ceil(JP/16)
 __global__ void __launch_bounds__(1024)
 k_project_triplane(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
@@ -537,6 +621,17 @@ extern "C" int fvp_project_whole(const float* heat_cl, const float* cams, const 
   if (B == 0) return 0;
   const int cpb = 256 / Z;
   ProfScope ps(FVP_K_PROJECT_WHOLE, as_stream(s));
+  static const bool no_quad = getenv("FVP_WHOLE_NO_QUAD") != nullptr;
+  const int nvl = ceil_div(g->JP, 16);
+  if (!no_quad && nvl <= 2) {
+    if (nvl == 1)
+      hipLaunchKernelGGL(k_project_whole_q<1>, dim3(ceil_div(X * Y, cpb), B), dim3(1024), 0, as_stream(s), heat_cl,
+                         reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, *g, cubes, zmax);
+    else
+      hipLaunchKernelGGL(k_project_whole_q<2>, dim3(ceil_div(X * Y, cpb), B), dim3(1024), 0, as_stream(s), heat_cl,
+                         reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, *g, cubes, zmax);
+    return launch_status();
+  }
 #define CALL(NV)                                                                                              \
   auto k = &k_project_whole<NV>;                                                                              \
   hipLaunchKernelGGL(k, dim3(ceil_div(X * Y, cpb), B), dim3(256), 0, as_stream(s), heat_cl,                   \
