@@ -64,6 +64,7 @@ struct ConvArgs {
   unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
   int tpp, tpr_log2;  // Winograd: 2x2 tiles per plane band of a workgroup, log2(tiles per row)
   int wino_ni;        // Winograd: input DMA rounds (of 512 x 16 B) per chunk
+  float* pool_dst;    // Winograd: if set, max_pool(2,2) of the output is written here too (one value per 2x2 tile)
   int wrow;           // k_conv_dma: floats per packed weight row (coutp, or 2*coutp for the paired transposed conv)
   unsigned m_tpp;
 };
@@ -808,6 +809,7 @@ static const int kNoDma = int(env_size("FVP_CONV_NO_DMA", 0));
 
 static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
+static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
 
 // Shapes the Winograd kernel covers: 3x3, even H, W a power of two in [8, 64*4] with W/2 dividing
@@ -939,8 +941,9 @@ static int plan_and_launch_tpair(const FvpConvOp& op, ConvArgs a, const float* p
 // Tile selection: all couts per workgroup (CB = coutp/32), PB so that CB*PB <= 8 accumulator
 // tiles per wave, the tile shaped to cover full image rows where possible.
 static int plan_and_launch(const FvpConvOp& op, const float* params, float* const* bufs, int planes,
-                           const uint8_t* plane_valid, int valid_div, hipStream_t s) {
+                           const uint8_t* plane_valid, int valid_div, hipStream_t s, float* pool_dst = nullptr) {
   ConvArgs a{};
+  a.pool_dst = pool_dst;
   const bool tr = op.kind == FVP_OP_CONVT2;
   const int kh = tr ? 1 : op.kh, kw = tr ? 1 : op.kw;
   a.src = bufs[op.src];
@@ -1073,10 +1076,14 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
     nconv += 1;
   }
   ProfScope stack_scope(FVP_K_CONV, as_stream(s), flops, nconv, prof_level() == 1);
+  // a 2x2 max-pool that reads the output of a Winograd conv is produced by that conv's epilogue
+  // (one pooled value per 2x2 output tile): the pool launch and its re-read of the map disappear
+  unsigned long long pooled = 0;                       // bit j: pool op j already done
   for (int i = 0; i < nops; ++i) {
     const FvpConvOp& op = ops[i];
     FVP_REQUIRE(op.src >= 0 && op.src < nbufs && op.dst >= 0 && op.dst < nbufs && op.res < nbufs);
     int rc;
+    if (op.kind == FVP_OP_POOL2 && i < 64 && ((pooled >> i) & 1)) continue;
     if (op.kind == FVP_OP_POOL2) {
       FVP_REQUIRE(op.w % 2 == 0 && (op.h == 1 || op.h % 2 == 0));
       const long total = long(planes) * op.cin * (op.h > 1 ? op.h / 2 : 1) * (op.w / 2);
@@ -1086,7 +1093,17 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
                          valid_div > 0 ? valid_div : 1, op.cin);
       rc = launch_status();
     } else if (op.kind == FVP_OP_CONV || op.kind == FVP_OP_CONVT2) {
-      rc = plan_and_launch(op, params, bufs, planes, plane_valid, valid_div, as_stream(s));
+      float* pool_dst = nullptr;
+      if (op.kind == FVP_OP_CONV && op.wino_off > 0 && !kNoWino && !kNoPoolFuse) {
+        for (int j = i + 1; j < nops && j < 64; ++j)
+          if (ops[j].kind == FVP_OP_POOL2 && ops[j].src == op.dst && ops[j].h == op.h && ops[j].w == op.w &&
+              ops[j].h > 1 && ops[j].cin == op.cout && ops[j].dst >= 0 && ops[j].dst < nbufs) {
+            pool_dst = bufs[ops[j].dst];
+            pooled |= 1ull << j;
+            break;
+          }
+      }
+      rc = plan_and_launch(op, params, bufs, planes, plane_valid, valid_div, as_stream(s), pool_dst);
     } else {
       rc = FVP_EINVAL;
     }

@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   const bool tile_ok = plane < a.planes;
   const unsigned pix = tile_ok ? unsigned(y * W + x) : 0u;
   const unsigned cbase = tile_ok ? unsigned(plane) * a.cout : 0u;
+  const unsigned ppix = unsigned((y >> 1) * (W >> 1) + tx);
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     unsigned off[4];
@@ -288,6 +289,8 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       if (ok[r]) {
         *reinterpret_cast<float2*>(a.dst + off[r]) = make_float2(o[0][0], o[0][1]);
         *reinterpret_cast<float2*>(a.dst + off[r] + W) = make_float2(o[1][0], o[1][1]);
+        if (a.pool_dst)                              // fused max_pool(2,2): this lane's tile is one pooled pixel
+          a.pool_dst[(cbase + co[r]) * unsigned(HW >> 2) + ppix] = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
       }
     }
   }
