@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight: step i runs on HIP stream i %% S with its own scratch buffers, so the "
                          "detection stage of one batch overlaps the joint stage of the previous one")
     ap.add_argument("--prof-steps", type=int, default=5,

@@ -22,6 +22,11 @@
 //                             ds_read_b128 of a lane (xi = 0..3) are bank-conflict free unpadded
 #pragma once
 
+// cache policy of the input-tile DMA (aux bits of global_load_lds); nt (= 2) measured 1 % slower
+#ifndef FVP_WINO_IN_AUX
+#define FVP_WINO_IN_AUX 0
+#endif
+
 namespace fvp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
         const bool ok = in_off[j] >= 0 && c0 + in_ci[j] < a.cin;
         const float* src = ok ? src_tile + size_t(c0) * HW + in_off[j] : a.zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, FVP_WINO_IN_AUX);
       }
     }
     const float* gw = wts + size_t(c0) * a.coutp * 16;

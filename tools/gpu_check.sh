@@ -13,7 +13,7 @@ echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== pytest -m gpu"; rm -f "$out/parity_report.jsonl"; timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -25 "$out/pytest_gpu.log"
 echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 3 > "$out/bench_${tag}.json" 2> "$out/bench_${tag}.err"; echo "bench rc=$?"; cat "$out/bench_${tag}.json"; tail -3 "$out/bench_${tag}.err"
 # sweeps: batch size at the default pipeline depth (2 batches in flight), and pipeline depth at B = 8 / B = 1
-for spec in "1 2" "2 2" "16 2" "32 2" "8 1" "8 3" "1 1" "1 4"; do
+for spec in "1 3" "2 3" "16 3" "32 3" "8 1" "8 2" "1 1" "1 4"; do
   set -- $spec; b=$1; st=$2
   timeout 600 python bench.py --steps 10 --warmup 3 --batch $b --streams $st --no-cpu-baseline > "$out/bench_${tag}_b${b}_s${st}.json" 2>> "$out/bench_${tag}.err"
   python - "$out/bench_${tag}_b${b}_s${st}.json" <<'PY'

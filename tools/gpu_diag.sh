@@ -1,9 +1,14 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+cp faster-voxelpose_amd/libfvp_hip.so /tmp/base.so
 (
-echo "=== pytest"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -2
 for i in 1 2; do
-echo "=== fuse s2"; python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-prof | cut -c80-130
-echo "=== nofuse s2"; FVP_CONV_NO_POOL_FUSE=1 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-prof | cut -c80-130
+cp /tmp/base.so faster-voxelpose_amd/libfvp_hip.so
+echo "=== base per-op"; python tools/bench_conv.py --ops 3,9,16 2>&1 | grep " op"
+echo "=== base s3"; python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
+cp tools/ab/libfvp_hip_nt.so faster-voxelpose_amd/libfvp_hip.so
+echo "=== nt per-op"; python tools/bench_conv.py --ops 3,9,16 2>&1 | grep " op"
+echo "=== nt s3"; python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
 done
-) > gpurun_out/diag33.log 2>&1
+cp /tmp/base.so faster-voxelpose_amd/libfvp_hip.so
+) > gpurun_out/diag35.log 2>&1
