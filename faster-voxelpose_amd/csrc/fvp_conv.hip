@@ -64,6 +64,8 @@ struct ConvArgs {
   unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
   int tpp, tpr_log2;  // Winograd: 2x2 tiles per plane band of a workgroup, log2(tiles per row)
   int wino_ni;        // Winograd: input DMA rounds (of 512 x 16 B) per chunk
+  int nunits, ysplit; // Winograd: work units (plane group x row band x cout block), cout blocks
+  unsigned m_ys, m_ty; // fdiv magics: ysplit, tiles_y
   float* pool_dst;    // Winograd: if set, max_pool(2,2) of the output is written here too (one value per 2x2 tile)
   int wrow;           // k_conv_dma: floats per packed weight row (coutp, or 2*coutp for the paired transposed conv)
   unsigned m_tpp;
@@ -852,6 +854,19 @@ static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   return res ? launch_wino2<WC, WT, 4, true>(a, grid, lds, s) : launch_wino2<WC, WT, 4, false>(a, grid, lds, s);
 }
 
+// one persistent 8-wave workgroup per CU
+static int persistent_workgroups() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = int(env_size("FVP_WINO_WGS", size_t(cus)));
+  }
+  return n;
+}
+
 static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
   int WC, WT, TN, TR;
   if (!wino_tiling(op.h, op.w, op.cinp, op.coutp, &WC, &WT, &TN, &TR)) return FVP_EINVAL;
@@ -886,7 +901,11 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   a.m_rpc = make_magic(TN * (a.TH + 2));
   a.m_thp = make_magic(a.TH + 2);
   const size_t lds = 16 + 3 * slot;
-  dim3 grid(a.tiles_y * ceil_div(planes, TN), op.coutp / CBW, 1);
+  a.ysplit = op.coutp / CBW;
+  a.nunits = a.tiles_y * ceil_div(planes, TN) * a.ysplit;
+  a.m_ys = make_magic(a.ysplit);
+  a.m_ty = make_magic(a.tiles_y);
+  dim3 grid(std::min(a.nunits, persistent_workgroups()), 1, 1);
   ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s) : launch_wino<2, 4>(a, grid, lds, s);
 }

@@ -65,14 +65,22 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   const int xs_sz = a.wino_ni * 2048;                // input slot, padded to whole DMA rounds (floats)
   const int buf_sz = xs_sz + WS_SZ;
 
-  const int tile = blockIdx.x;
-  const int pg = tile / a.tiles_y;
-  const int ty_i = tile - pg * a.tiles_y;
-  const int plane0 = pg * a.TN;
-  const int y0 = ty_i * a.TH;
-  const int co0 = blockIdx.y * CBW;
-  if (a.plane_valid && a.TN == 1 && !a.plane_valid[plane0 / a.valid_div]) return;
-  const float* wts = a.wts + size_t(co0) * 16;       // [cinp][coutp][16]
+  // Persistent workgroups: unit u = (plane group, row band, cout block); workgroup b walks
+  // u = b, b + G, b + 2G, ... (G = gridDim.x <= number of CUs).  The chunk stream (DMA two chunks
+  // ahead) runs across unit boundaries, so a unit's first chunks land while the previous unit is
+  // still computing and there is no workgroup relaunch between tiles.
+  const int G = gridDim.x, nunits = a.nunits;
+  auto unit_valid = [&](int u) {
+    if (!a.plane_valid || a.TN != 1) return true;
+    const int pg = fdiv(fdiv(u, a.m_ys), a.m_ty);
+    return a.plane_valid[pg / a.valid_div] != 0;
+  };
+  auto next_unit = [&](int u) {
+    while (u < nunits && !unit_valid(u)) u += G;
+    return u;
+  };
+  int u = next_unit(blockIdx.x);
+  if (u >= nunits) return;
 
   // this lane's 2x2 output tile inside the workgroup tile (exact cover: 16*WT = TN * tpp)
   const int q = wt * 16 + l15;
@@ -101,40 +109,47 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   const int nps = a.wino_ni + NW;                    // DMA instructions per wave per chunk (uniform)
 
   constexpr int kMaxIn = 4;                          // host guarantees wino_ni <= kMaxIn
-  int in_off[kMaxIn], in_ci[kMaxIn];
+  // unit-invariant part of this lane's input DMA items: offset relative to the unit's first
+  // (plane, channel chunk, row band) and {row in slot, plane in group, channel in chunk}
+  int rel_off[kMaxIn], meta[kMaxIn];
 #pragma unroll
   for (int j = 0; j < kMaxIn; ++j) {
     const int it = (wave + 8 * j) * 64 + lane;
-    in_off[j] = -1;                                  // zero page: margins, halo rows, padding items
-    in_ci[j] = 0;
+    rel_off[j] = 0;
+    meta[j] = -1;                                    // zero page: margins, padding items
     if (it < nin) {
       const int row = fdiv(it, a.m_qpr), qd = it - row * qpr;
       const int ci = fdiv(row, a.m_rpc);
       const int rem = row - ci * rows_per_ch;
       const int n = fdiv(rem, a.m_thp), ry = rem - n * THp;
-      const int plane = plane0 + n, y = y0 + ry - 1;
-      in_ci[j] = ci;
-      if (qd > 0 && ci < CC && plane < a.planes && y >= 0 && y < a.H)
-        in_off[j] = (n * a.cin + ci) * HW + y * W + 4 * (qd - 1);
+      if (qd > 0 && ci < CC) {
+        rel_off[j] = (n * a.cin + ci) * HW + (ry - 1) * W + 4 * (qd - 1);
+        meta[j] = ry | (n << 8) | (ci << 16);
+      }
     }
   }
-  const float* src_tile = a.src + size_t(plane0) * a.cin * HW;
   // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
-  auto stage = [&](int k, int boff) {
+  auto stage = [&](int su, int k, int boff) {
+    const int st = fdiv(su, a.m_ys), sy = su - st * a.ysplit;
+    const int spg = fdiv(st, a.m_ty), sty = st - spg * a.tiles_y;
+    const int splane0 = spg * a.TN, sy0 = sty * a.TH;
     float* xs = smem + 4 + boff;
     float* ws = xs + xs_sz;
     const int c0 = k * CC;
+    const float* src_unit = a.src + (size_t(splane0) * a.cin + c0) * HW + sy0 * W;
 #pragma unroll
     for (int j = 0; j < kMaxIn; ++j) {
       if (j < a.wino_ni) {
         const int g = wave + 8 * j;
-        const bool ok = in_off[j] >= 0 && c0 + in_ci[j] < a.cin;
-        const float* src = ok ? src_tile + size_t(c0) * HW + in_off[j] : a.zeros;
+        const int ry = meta[j] & 255, n = (meta[j] >> 8) & 255, ci = meta[j] >> 16;
+        const bool ok = meta[j] >= 0 && unsigned(sy0 + ry - 1) < unsigned(a.H) && splane0 + n < a.planes &&
+                        c0 + ci < a.cin;
+        const float* src = ok ? src_unit + rel_off[j] : a.zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, FVP_WINO_IN_AUX);
       }
     }
-    const float* gw = wts + size_t(c0) * a.coutp * 16;
+    const float* gw = a.wts + size_t(sy) * (CBW * 16) + size_t(c0) * a.coutp * 16;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int g = wave + 8 * j;
@@ -144,6 +159,17 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(ws + g * 256), 16, 0, 0);
     }
+  };
+  // cursor of the chunk stream the DMA follows (unit, chunk)
+  int su = u, sk = 0;
+  auto stage_next = [&](int boff) {
+    if (su >= nunits) return false;
+    stage(su, sk, boff);
+    if (++sk == nchunks) {
+      sk = 0;
+      su = next_unit(su + G);
+    }
+    return true;
   };
 
   // ---- operand fetch / transform / MFMA building blocks
@@ -180,21 +206,22 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
     }
   };
 
-  // ---- three chunk slots: chunk k+2 streams in while chunk k is consumed
+  // ---- three chunk slots: chunk g+2 streams in while chunk g is consumed
   const bool dma = !(a.ablate & 1);
   if (dma) {
-    stage(0, 0);
-    if (nchunks > 1) stage(1, buf_sz);
-    wait_vmcnt(nchunks > 1 ? nps : 0);
+    stage_next(0);
+    const bool second = stage_next(buf_sz);
+    wait_vmcnt(second ? nps : 0);
   }
   __syncthreads();
   int cur_off = 0;
   fetch_a(0, smem + 4, 0);
   fetch_d(smem + 4, 0, WP);
+  while (true) {
   for (int k = 0; k < nchunks; ++k) {
     const int nxt_off = cur_off + buf_sz >= 3 * buf_sz ? 0 : cur_off + buf_sz;
     const int nn_off = nxt_off + buf_sz >= 3 * buf_sz ? 0 : nxt_off + buf_sz;
-    if (k + 2 < nchunks && dma) stage(k + 2, nn_off);
+    const bool more = dma && stage_next(nn_off);
     const float* cur = smem + 4 + cur_off;
     const float* nxt = smem + 4 + nxt_off;
     int wp = WP;
@@ -221,11 +248,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
         fetch_a(0, cur, s + 1);
       } else {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
-        // may be overwritten by the DMA of chunk k+3, and chunk k+1 has landed for everybody
-        if (dma) wait_vmcnt(k + 2 < nchunks ? nps : 0);
+        // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
+        if (dma) wait_vmcnt(more ? nps : 0);
         __syncthreads();
-        fetch_a(0, nxt, 0);
-        fetch_d(nxt, 0, wp);
+        if (k + 1 < nchunks) {                       // (a unit's last chunk: the epilogue needs the registers)
+          fetch_a(0, nxt, 0);
+          fetch_d(nxt, 0, wp);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma16(1);
@@ -234,8 +263,14 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
     cur_off = nxt_off;
   }
 
-  if (a.ablate & 8) return;
-  // ---- output transform + epilogue, per lane: tile (plane, y, x), 8 couts
+  // ---- unit finished: output transform + epilogue, then the next unit of this workgroup
+  int ue = u;
+  FVP_OPAQUE(ue);                                    // keeps the epilogue's address math out of the K loop's live set
+  const int ut = fdiv(ue, a.m_ys), uy = ue - ut * a.ysplit;
+  const int pg = fdiv(ut, a.m_ty), ty_i = ut - pg * a.tiles_y;
+  const int plane0 = pg * a.TN, y0 = ty_i * a.TH, co0 = uy * CBW;
+  if (!(a.ablate & 8)) {
+  // per lane: tile (plane, y, x), 8 couts
   const float* bias = a.epi;
   const float* scale = a.epi + a.coutp;
   const float* shift = a.epi + 2 * a.coutp;
@@ -298,6 +333,18 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
           a.pool_dst[(cbase + co[r]) * unsigned(HW >> 2) + ppix] = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
       }
     }
+  }
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[cb][p][r] = 0.0f;
+  u = next_unit(u + G);
+  if (u >= nunits) break;
+  fetch_a(0, smem + 4 + cur_off, 0);
+  fetch_d(smem + 4 + cur_off, 0, WP);
   }
 }
 

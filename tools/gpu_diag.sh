@@ -1,14 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-cp faster-voxelpose_amd/libfvp_hip.so /tmp/base.so
 (
+echo "=== pytest"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -2
 for i in 1 2; do
-cp /tmp/base.so faster-voxelpose_amd/libfvp_hip.so
-echo "=== base per-op"; python tools/bench_conv.py --ops 3,9,16 2>&1 | grep " op"
-echo "=== base s3"; python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
-cp tools/ab/libfvp_hip_nt.so faster-voxelpose_amd/libfvp_hip.so
-echo "=== nt per-op"; python tools/bench_conv.py --ops 3,9,16 2>&1 | grep " op"
-echo "=== nt s3"; python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
+echo "=== persistent s1"; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1 --no-prof| cut -c80-130
+echo "=== one-unit s1"; FVP_WINO_WGS=1000000 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1 --no-prof| cut -c80-130
+echo "=== persistent s3"; python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
+echo "=== one-unit s3"; FVP_WINO_WGS=1000000 python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
 done
-cp /tmp/base.so faster-voxelpose_amd/libfvp_hip.so
-) > gpurun_out/diag35.log 2>&1
+) > gpurun_out/diag37.log 2>&1
