@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfvp_hip.so"
+ABI_VERSION = 2            # include/fvp.h FVP_ABI_VERSION
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 FVP_CAM_FLOATS = 24
@@ -41,6 +42,7 @@ _G = C.POINTER(FvpGeom)
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/fvp.h 1:1
 SIGNATURES = {
     "fvp_version": [],
+    "fvp_sizeof": [_I],
     "fvp_error_string": [_I],
     "fvp_heatmaps_to_cl": [_P, _P, _I, _G, _P],
     "fvp_sample_grid": [_P, _P, _P, _I, _I, _I, _P, _G, _P, _P],
@@ -91,8 +93,10 @@ def load():
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`faster-voxelpose_amd/csrc/build.sh`.")
         _lib = bind(C.CDLL(LIB_PATH))
-        if _lib.fvp_version() != 1:
-            raise FvpError("libfvp_hip.so ABI version mismatch")
+        if _lib.fvp_version() != ABI_VERSION:
+            raise FvpError("libfvp_hip.so ABI version mismatch (rebuild with faster-voxelpose_amd/csrc/build.sh)")
+        if _lib.fvp_sizeof(0) != C.sizeof(FvpGeom) or _lib.fvp_sizeof(1) != C.sizeof(FvpConvOp):
+            raise FvpError("libfvp_hip.so struct layout differs from the ctypes mirrors in _capi.py")
     return _lib
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FVP_ABI_VERSION 1
+#define FVP_ABI_VERSION 2
 #define FVP_MAX_VIEWS 8
 #define FVP_CAM_FLOATS 24 /* R[9] T[3] fx fy cx cy k[3] p[2] + 3 pad */
 #define FVP_MAX_JOINTS 32
@@ -48,6 +48,9 @@ typedef struct FvpGeom {
 } FvpGeom;
 
 int fvp_version(void);
+/* sizeof(FvpGeom) (what = 0) / sizeof(FvpConvOp) (what = 1) as compiled into the library: lets a
+ * binding check its struct mirrors before passing them. */
+int fvp_sizeof(int what);
 const char* fvp_error_string(int code);
 
 /* ---- staging ------------------------------------------------------------------------

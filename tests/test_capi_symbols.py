@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/fvp.h but missing from libfvp_hip.so"
     capi.bind(lib)
-    assert lib.fvp_version() == 1
+    assert lib.fvp_version() == capi.ABI_VERSION
+    assert lib.fvp_sizeof(0) == ctypes.sizeof(capi.FvpGeom) and lib.fvp_sizeof(1) == ctypes.sizeof(capi.FvpConvOp)
     assert b"invalid argument" in lib.fvp_error_string(10001)
 
 

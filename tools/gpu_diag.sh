@@ -1,8 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 (
-for w in 256 240 224 192 512; do
-echo "=== wgs $w s3"; FVP_WINO_WGS=$w python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
+echo "=== conv per-op"; python tools/bench_conv.py --ops 3,4,5,9,10,15,16 2>&1 | grep " op"
+echo "=== pytest"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -2
+for i in 1 2; do
+echo "=== s1"; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1 --no-prof| cut -c80-130
+echo "=== s3"; python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-prof | cut -c80-130
 done
-echo "=== wgs 512 s1";  FVP_WINO_WGS=512 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1 --no-prof| cut -c80-130
-) > gpurun_out/diag38.log 2>&1
+) > gpurun_out/diag39.log 2>&1
