@@ -61,6 +61,7 @@ SIGNATURES = {
     "fvp_softargmax_weightnet": [_P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "fvp_pack_weightnet": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P, _P],
     "fvp_fuse_poses": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "fvp_rasterise_heatmaps": [_P, _P, _I, _I, _I, _I, _I, C.c_double, C.c_double, C.c_double, _P, _P, _I, _P],
     "fvp_prof_enable": [_I],
     "fvp_prof_read": [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
     "fvp_prof_reset": [],

@@ -223,6 +223,17 @@ int fvp_fuse_poses(const float* pose2d, const float* pmax, const float* wgt, con
                    const uint8_t* person_valid, int nP, int J, float* centers, float* fused_poses,
                    float* plane_poses, fvp_stream_t s);
 
+/* ---- "next" row f-2: input heatmaps rasterised from 2-D detections ------------------------------------
+ * joints [nimg][P][J][2] float64 in NETWORK-image pixels (already through the resize affine, as
+ * JointsDataset.py:149-151 leaves them), num_people [nimg] <= P.  Writes Gaussian heatmaps
+ * [nimg][J][H][W] (heat_nchw, the reference layout) and / or the channels-last staging copy
+ * [nimg][H*W][JP] the projection kernels read (heat_cl; either may be NULL).  Replaces
+ * JointsDataset.generate_input_heatmap (lib/dataset/JointsDataset.py:271-338, eval branch) and
+ * compute_human_scale (:197-203); float64 scalar arithmetic like numpy, one rounding to fp32. */
+int fvp_rasterise_heatmaps(const double* joints, const int32_t* num_people, int nimg, int P, int J, int W, int H,
+                           double feat_stride_x, double feat_stride_y, double sigma, float* heat_nchw,
+                           float* heat_cl, int JP, fvp_stream_t s);
+
 /* ---- measurement hooks (bench.py roofline leg) -----------------------------------------------------
  * fvp_prof_enable(1): kernel classes are bracketed by hipEvents on the stream they are launched
  * on -- per launch for the projection / soft-argmax / small kernels, one pair per

@@ -532,3 +532,69 @@ def reference_state_dict_shapes(cfg):
     out[wn + ".output.2.weight"] = torch.zeros(1, Hd)
     out[wn + ".output.2.bias"] = torch.zeros(1)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# "next" row f-2: input heatmaps rasterised from 2-D detections (precomputed-heatmap path)
+# --------------------------------------------------------------------------------------
+def compute_human_scale(pose, joints_vis):
+    """lib/dataset/JointsDataset.py:197-203."""
+    idx = joints_vis > 0.1
+    if np.sum(idx) == 0:
+        return 0
+    minx, maxx = np.min(pose[idx, 0]), np.max(pose[idx, 0])
+    miny, maxy = np.min(pose[idx, 1]), np.max(pose[idx, 1])
+    return np.clip(np.maximum(maxy - miny, maxx - minx) ** 2, 1.0 / 4 * 96 ** 2, 4 * 96 ** 2)
+
+
+def generate_input_heatmap(joints, image_size, heatmap_size, sigma):
+    """One view: list of [J,>=2] joints in network-image pixels -> [J,H,W] float32
+    (JointsDataset.generate_input_heatmap :271-338, eval path: no joints_vis, no augmentation).
+    The expressions are kept literally so that numpy's dtype promotion (float32 ``arange``
+    against float64 scalars) is the reference's under the numpy installed here."""
+    image_size, heatmap_size = np.array(image_size), np.array(heatmap_size)
+    num_joints = joints[0].shape[0]
+    target = np.zeros((num_joints, heatmap_size[1], heatmap_size[0]), dtype=np.float32)
+    feat_stride = image_size / heatmap_size
+    for n in range(len(joints)):
+        human_scale = 2 * compute_human_scale(joints[n][:, :2] / feat_stride, np.ones(num_joints))
+        if human_scale == 0:
+            continue
+        cur_sigma = sigma * np.sqrt((human_scale / (96.0 * 96.0)))
+        tmp_size = cur_sigma * 3
+        for joint_id in range(num_joints):
+            mu_x = int(joints[n][joint_id][0] / feat_stride[0])
+            mu_y = int(joints[n][joint_id][1] / feat_stride[1])
+            ul = [int(mu_x - tmp_size), int(mu_y - tmp_size)]
+            br = [int(mu_x + tmp_size + 1), int(mu_y + tmp_size + 1)]
+            if ul[0] >= heatmap_size[0] or ul[1] >= heatmap_size[1] or br[0] < 0 or br[1] < 0:
+                continue
+            size = 2 * tmp_size + 1
+            x = np.arange(0, size, 1, np.float32)
+            y = x[:, np.newaxis]
+            x0 = y0 = size // 2
+            g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * cur_sigma ** 2))
+            g_x = max(0, -ul[0]), min(br[0], heatmap_size[0]) - ul[0]
+            g_y = max(0, -ul[1]), min(br[1], heatmap_size[1]) - ul[1]
+            img_x = max(0, ul[0]), min(br[0], heatmap_size[0])
+            img_y = max(0, ul[1]), min(br[1], heatmap_size[1])
+            target[joint_id][img_y[0]:img_y[1], img_x[0]:img_x[1]] = np.maximum(
+                target[joint_id][img_y[0]:img_y[1], img_x[0]:img_x[1]], g[g_y[0]:g_y[1], g_x[0]:g_x[1]])
+        target = np.clip(target, 0, 1)
+    return target
+
+
+def input_heatmaps_from_pred2d(all_preds, resize_transform, image_size, heatmap_size, sigma):
+    """All views of one frame: ``db_rec['pred_pose2d']`` (list over views of lists of [J,>=2]
+    arrays in ORIGINAL image pixels) -> [V,J,H,W] (JointsDataset.__getitem__ :144-154:
+    affine_transform of every joint, then generate_input_heatmap per view)."""
+    t = np.asarray(resize_transform, np.float64)
+    out = []
+    for preds in all_preds:
+        preds = [np.array(p, dtype=np.float64, copy=True) for p in preds]
+        for n in range(len(preds)):
+            for i in range(len(preds[n])):
+                new_pt = np.array([preds[n][i, 0], preds[n][i, 1], 1.0]).T
+                preds[n][i, :2] = np.dot(t, new_pt)[:2]                    # utils/transforms.py:53-56
+        out.append(torch.from_numpy(generate_input_heatmap(preds, image_size, heatmap_size, sigma)))
+    return torch.stack(out, dim=0)

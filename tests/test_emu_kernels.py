@@ -3,6 +3,7 @@ against tests/hipemu, driven through the same C ABI and the same Python host cod
 product, compared with the golden vectors and the oracle.  (The emulator is test
 infrastructure; the product never loads it.)"""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -136,3 +137,20 @@ def test_fused_c2c_equals_generic_interpreter(emu_lib):
     generic = model.pose_net.c2c_net(z)
     assert torch.equal(fused, generic)
     np.testing.assert_allclose(fused.numpy(), O.c2c_net(sd, "pose_net.c2c_net", z).numpy(), rtol=3e-6, atol=3e-6)
+
+
+def test_rasteriser_kernel_matches_reference_golden(emu_lib):
+    """fvp_rasterise_heatmaps (emulated) vs the reference's generate_input_heatmap outputs: exact."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from heatmap_cases import HEATMAP_CASES, make_pred2d
+    from faster_voxelpose_amd.dataset import generate_input_heatmaps
+    for case in HEATMAP_CASES:
+        cfg, all_preds, rt, sigma = make_pred2d(case)
+        g = load_golden(case)["heatmaps"]
+        hm, cl = generate_input_heatmaps(all_preds, rt, cfg, sigma=sigma, device="cpu", channels_last=True, _lib=emu_lib)
+        assert np.array_equal(hm.numpy(), g), case
+        J = cfg.DATASET.NUM_JOINTS
+        V, _, H, W = g.shape
+        assert np.array_equal(cl.numpy()[..., :J], g.reshape(V, J, H * W).transpose(0, 2, 1))
+        assert not cl.numpy()[..., J:].any()

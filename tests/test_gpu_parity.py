@@ -249,3 +249,28 @@ def test_standalone_softargmax_and_weightnet_vs_oracle():
     np.testing.assert_allclose(pose.cpu().numpy(), want_pose.numpy(), rtol=0, atol=2e-2)     # mm
     np.testing.assert_allclose(confs.cpu().numpy(), want_conf.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(w.cpu().numpy(), want_w.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["hm_shelf_p4", "hm_campus_p3", "hm_panoptic_p6"])
+def test_rasteriser_vs_reference_golden(case):
+    """GPU heatmap rasteriser (fvp_rasterise_heatmaps) vs the reference's generate_input_heatmap:
+    windows are placed with exact float64 arithmetic, values are exp(double) rounded once to fp32
+    (bit-equal up to the device libm's last float64 bit: <= 1 ulp of float32 allowed)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from heatmap_cases import make_pred2d
+    from faster_voxelpose_amd.dataset import generate_input_heatmaps
+    cfg, all_preds, rt, sigma = make_pred2d(case)
+    cfg.DEVICE = "cuda:0"
+    g = load_golden(case)["heatmaps"]
+    hm, cl = generate_input_heatmaps(all_preds, rt, cfg, sigma=sigma, channels_last=True)
+    got = hm.cpu().numpy()
+    assert np.array_equal(got > 0, g > 0), "window placement differs"
+    np.testing.assert_allclose(got, g, rtol=1.2e-7, atol=1e-45)
+    J = cfg.DATASET.NUM_JOINTS
+    V, _, H, W = g.shape
+    assert np.array_equal(cl.cpu().numpy()[..., :J], got.reshape(V, J, H * W).transpose(0, 2, 1))
+    # batched call = per-frame calls
+    hm2 = generate_input_heatmaps([all_preds, all_preds], rt, cfg, sigma=sigma)
+    assert torch.equal(hm2[0], hm) and torch.equal(hm2[1], hm)

@@ -83,3 +83,25 @@ def test_nms_tie_rule_and_padding():
     assert flat[0].tolist()[:3] == [0, 21, 22]
     assert vals[0].tolist()[:3] == [1.0, 1.0, 1.0]
     assert idx[0, 1].tolist() == [3, 3]
+
+
+# ---- "next" row f-2: input heatmaps rasterised from 2-D detections ---------------------------------
+from heatmap_cases import HEATMAP_CASES, make_pred2d  # noqa: E402
+
+
+@pytest.mark.parametrize("case", list(HEATMAP_CASES))
+def test_oracle_rasteriser_matches_reference_golden(case):
+    """The oracle's restatement of JointsDataset.generate_input_heatmap (+ affine_transform of the
+    detections) reproduces the reference's heatmaps bit for bit."""
+    cfg, all_preds, rt, sigma = make_pred2d(case)
+    g = load_golden(case)
+    views = [p if len(p) else None for p in all_preds]
+    out = []
+    for preds in views:
+        if preds is None:                       # a view without detections: the reference would index joints[0]
+            out.append(torch.zeros(cfg.DATASET.NUM_JOINTS, cfg.DATASET.HEATMAP_SIZE[1], cfg.DATASET.HEATMAP_SIZE[0]))
+        else:
+            out.append(O.input_heatmaps_from_pred2d([preds], rt, cfg.DATASET.IMAGE_SIZE, cfg.DATASET.HEATMAP_SIZE, sigma)[0])
+    hm = torch.stack(out).numpy()
+    assert hm.dtype == np.float32 and hm.shape == g["heatmaps"].shape
+    assert np.array_equal(hm, g["heatmaps"])
