@@ -274,3 +274,41 @@ def test_rasteriser_vs_reference_golden(case):
     # batched call = per-frame calls
     hm2 = generate_input_heatmaps([all_preds, all_preds], rt, cfg, sigma=sigma)
     assert torch.equal(hm2[0], hm) and torch.equal(hm2[1], hm)
+
+
+@pytest.mark.gpu
+def test_precomputed_heatmap_path_end_to_end_shelf():
+    """BASELINE configs[2] shape (Shelf, 'pred' heatmap source): 2-D detections -> GPU rasteriser ->
+    hot path -> PCP evaluator, through core.function.validate; compared with the CPU oracle fed with
+    the oracle's own rasterised heatmaps."""
+    import functools
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from heatmap_cases import make_pred2d
+    from faster_voxelpose_amd.core import function as FN, metrics as M
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg, all_preds, rt, sigma = make_pred2d("hm_shelf_p4")
+    all_preds = [v if len(v) else [np.zeros((cfg.DATASET.NUM_JOINTS, 3))] for v in all_preds]   # every view has a detection
+    cfg.DEVICE = "cuda:0"
+    cfg.CAPTURE_SPEC.MIN_SCORE = -1.0
+    cfg.NETWORK.SIGMA = sigma
+    cams, seq = S.load_cameras("shelf")
+    model = FV.get(cfg).to("cuda:0")
+    sd = S.fill_state_dict(model.state_dict(), seed=11)
+    model.load_state_dict(sd)
+    batches = [dict(meta={"seq": [seq, seq]}, pred_pose2d=[all_preds, all_preds]),
+               dict(meta={"seq": [seq]}, pred_pose2d=[all_preds])]
+    actors = [[np.random.default_rng(a).normal(0, 500, (14, 3)) for _ in range(3)] for a in range(4)]
+    metric, fused, info = FN.validate(cfg, model, batches, cams, rt, depth=2,
+                                      evaluate=functools.partial(M.evaluate_pcp, actors_mm=actors))
+    assert fused.shape == (3, cfg.CAPTURE_SPEC.MAX_PEOPLE, cfg.DATASET.NUM_JOINTS, 5) and info["frames"] == 3
+    assert 0.0 <= metric <= 1.0 and set(info["evaluation"]) >= {"actor_pcp", "recall"}
+    assert torch.equal(fused[0], fused[1]) and torch.equal(fused[0], fused[2])       # same frame three times
+    # oracle: its own rasteriser + its own pipeline
+    cfg_cpu = S.make_cfg("shelf", device="cpu", min_score=-1.0)
+    hm = O.input_heatmaps_from_pred2d(all_preds, rt, cfg_cpu.DATASET.IMAGE_SIZE, cfg_cpu.DATASET.HEATMAP_SIZE, sigma)
+    of, _, oc = O.Oracle(cfg_cpu, {k: v.cpu() for k, v in sd.items()}).forward(
+        hm[None], {"seq": [seq]}, cams, torch.as_tensor(rt, dtype=torch.float32))
+    v = oc[0, :, 3] >= 0
+    err = (fused[0].cpu()[v][..., :3] - of[0][v][..., :3]).norm(dim=-1).max().item()
+    assert err < 5e-2, err
