@@ -18,7 +18,9 @@ FVP_MAX_JOINTS = 32
 
 OP_CONV, OP_POOL2, OP_CONVT2 = 0, 1, 2
 EPI_RELU, EPI_RES, EPI_RES_AFTER_RELU = 1, 2, 4
-K_PROJECT_WHOLE, K_PROJECT_TRIPLANE, K_CONV, K_SOFTARGMAX, K_OTHER, K_CONV_WINO, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+K_PROJECT_WHOLE, K_PROJECT_TRIPLANE, K_CONV, K_SOFTARGMAX, K_OTHER, K_CONV_WINO, K_BACKBONE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+BB_CONV, BB_MAXPOOL, BB_DECONV = 0, 1, 2
+BB_OUT_HEAT = 8
 
 
 class FvpGeom(C.Structure):
@@ -32,6 +34,11 @@ class FvpConvOp(C.Structure):
                 ("cin", C.c_int32), ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("h", C.c_int32), ("w", C.c_int32), ("flags", C.c_int32), ("w_off", C.c_int32),
                 ("e_off", C.c_int32), ("cinp", C.c_int32), ("coutp", C.c_int32), ("wino_off", C.c_int32), ("pair_off", C.c_int32)]
+
+
+class FvpBbOp(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "src", "dst", "res", "cin", "cinp", "cout", "coutp", "cbuf", "kh", "kw",
+                                         "stride", "pad", "h", "w", "oh", "ow", "flags", "w_off", "e_off")]
 
 
 _P = C.c_void_p
@@ -62,6 +69,9 @@ SIGNATURES = {
     "fvp_pack_weightnet": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P, _P],
     "fvp_fuse_poses": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "fvp_rasterise_heatmaps": [_P, _P, _I, _I, _I, _I, _I, C.c_double, C.c_double, C.c_double, _P, _P, _I, _P],
+    "fvp_bb_input": [_P, _P, _I, _I, _I, _I, _P],
+    "fvp_bb_pack": [_P, _P, _P, _P, _P, _P, _F, C.POINTER(FvpBbOp), _P, _P, _P],
+    "fvp_bb_run": [C.POINTER(FvpBbOp), _I, _P, _P, C.POINTER(_P), _I, _I, _P, _I, _P, _P],
     "fvp_prof_enable": [_I],
     "fvp_prof_read": [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
     "fvp_prof_reset": [],

@@ -4,7 +4,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${here}/../libfvp_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-srcs=(fvp_capi.hip fvp_project.hip fvp_conv.hip fvp_conv1d_fused.hip fvp_proposal.hip fvp_joint.hip fvp_heatmap.hip)
+srcs=(fvp_capi.hip fvp_project.hip fvp_conv.hip fvp_conv1d_fused.hip fvp_proposal.hip fvp_joint.hip fvp_heatmap.hip fvp_backbone.hip)
 objs=()
 for s in "${srcs[@]}"; do
   o="${here}/${s%.hip}.o"

@@ -1,0 +1,412 @@
+// Pose-ResNet backbone (lib/models/resnet.py:98-215) in bf16 on the matrix cores: every conv /
+// transposed conv is an implicit GEMM  D[pixel][cout] = sum_k X[pixel][k] * W[cout][k]  over NHWC
+// bf16 activations, k = (tap, cin), on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; eval
+// BatchNorm (folded to scale / shift), residual add and ReLU run in the epilogue.
+//
+//   A operand = pixels  (row i = pixel: lane l holds X[l&31][8*(l>>5) .. +7] of a 16-wide k step)
+//   B operand = weights (col j = cout,  same k mapping), packed [cout][k] so that both operands are
+//               read from LDS as one ds_read_b128 per lane
+//   D         : lane l holds cout column l&31 and pixel rows (r&3) + 8*(r>>2) + 4*(l>>5): 32 lanes
+//               store 32 consecutive channels of one pixel = 64 contiguous bytes of NHWC
+//
+// Workgroup = 4 waves (2 x 2), tile 128 pixels x 128 couts (64 for the 64-channel layers), k chunks
+// of 32 through two LDS buffers with an 80-byte row pitch (conflict-free b128 reads); the next
+// chunk's global loads are in flight while the current one is multiplied.  A per-launch tap table
+// (dy, dx) covers strided convs and the four parity classes of ConvTranspose(k4, s2, p1) with the
+// same kernel; the last layer writes fp32 heatmaps directly in the channels-last layout the
+// projection kernels read (and / or NCHW, the reference's layout).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "fvp_common.h"
+
+namespace fvp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct alignas(16) Bf8 { uint32_t w[4]; };          // 8 bf16
+
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even
+  uint32_t u = uint32_t(__float_as_int(f));
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return uint16_t(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __int_as_float(int(uint32_t(h) << 16)); }
+
+__device__ __forceinline__ f32x16 mfma_bf16(const Bf8& a, const Bf8& b, f32x16 c) {
+#if defined(__AMDGCN__)
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#else
+  return hipemu_mfma_32x32x16_bf16(a.w, b.w, c);
+#endif
+}
+
+struct BbConvArgs {
+  const uint16_t* in;
+  uint16_t* out;
+  float* out_cl;          // fp32 [N][ROH*ROW][out_jp] (last layer) or null
+  float* out_nchw;        // fp32 [N][Cout][ROH][ROW] (last layer) or null
+  const uint16_t* res;
+  const uint16_t* w;      // [Coutp][K]
+  const float* epi;       // scale | shift, each Coutp
+  int N, H, W, Cinp, cin_log2;
+  int OH, OW;             // grid the GEMM rows walk (output grid; input grid for a transposed-conv class)
+  int ROH, ROW, Cbuf;     // real output tensor dims (NHWC, Cbuf channels)
+  int Cout, Coutp;
+  int stride, os, py, px; // input pixel = o*stride + d ; output pixel = o*os + p
+  int ntaps, K, relu, out_jp;
+  unsigned m_ow, m_ohw;   // fdiv magics: OW, OH*OW
+  signed char dy[64], dx[64];
+};
+
+__device__ __forceinline__ int bb_fdiv(int x, unsigned magic) { return magic ? int(__umulhi(unsigned(x), magic)) : x; }
+
+template <int BN>
+__global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
+  constexpr int BM = 128, BK = 32, LP = 40;           // LDS row pitch in bf16 (80 bytes)
+  constexpr int WN = BN / 2;                          // couts per wave: 64 or 32
+  constexpr int NJ = WN / 32;                         // cout tiles per wave
+  __shared__ __attribute__((aligned(16))) uint16_t As[2][BM][LP];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN][LP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = a.N * a.OH * a.OW;
+  const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+
+  // ---- this thread's staging duty: one pixel row (two 8-wide k groups) and one weight row
+  const int arow = t >> 1, ag = (t & 1) * 2;
+  const int am = m0 + arow;
+  const bool arow_ok = am < M;
+  int an, aoy, aox;
+  {
+    const int mm = arow_ok ? am : 0;
+    an = bb_fdiv(mm, a.m_ohw);
+    const int r = mm - an * (a.OH * a.OW);
+    aoy = bb_fdiv(r, a.m_ow);
+    aox = r - aoy * a.OW;
+  }
+  const int brow = t >> 1;                            // < BN for BN = 128; for BN = 64 rows 64.. are skipped
+  const bool brow_ok = brow < BN;
+  const uint16_t* wrow = a.w + size_t(co0 + (brow_ok ? brow : 0)) * a.K;
+
+  Bf8 ra[2], rb[2];
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kk = chunk * BK + (ag + u) * 8;
+      Bf8 v{{0u, 0u, 0u, 0u}};
+      if (kk < a.K && arow_ok) {
+        const int tap = kk >> a.cin_log2, c0 = kk & (a.Cinp - 1);
+        const int iy = aoy * a.stride + a.dy[tap], ix = aox * a.stride + a.dx[tap];
+        if (unsigned(iy) < unsigned(a.H) && unsigned(ix) < unsigned(a.W))
+          v = *reinterpret_cast<const Bf8*>(a.in + (size_t(an * a.H + iy) * a.W + ix) * a.Cinp + c0);
+      }
+      ra[u] = v;
+      Bf8 wv{{0u, 0u, 0u, 0u}};
+      if (kk < a.K && brow_ok) wv = *reinterpret_cast<const Bf8*>(wrow + kk);
+      rb[u] = wv;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *reinterpret_cast<Bf8*>(&As[buf][arow][(ag + u) * 8]) = ra[u];
+      if (brow_ok) *reinterpret_cast<Bf8*>(&Bs[buf][brow][(ag + u) * 8]) = rb[u];
+    }
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nchunks = (a.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) gload(c + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Bf8 fa[2], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const Bf8*>(&As[buf][wm * 64 + i * 32 + l31][ks * 16 + 8 * half]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const Bf8*>(&Bs[buf][wn * WN + j * 32 + l31][ks * 16 + 8 * half]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
+    }
+    if (c + 1 < nchunks) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: BN scale / shift, residual, ReLU; NHWC bf16 (or fp32 heatmaps for the last layer)
+  const float* scale = a.epi;
+  const float* shift = a.epi + a.Coutp;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int co = co0 + wn * WN + j * 32 + l31;
+    const float sc = scale[co], sh = shift[co];        // epi vectors are padded to Coutp
+    const bool co_ok = co < a.Cout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= M) continue;
+        size_t pix;                                    // pixel index in the real output tensor
+        int n_ = 0;
+        if (a.os == 1) {
+          pix = size_t(m);
+          if (a.out_nchw) n_ = bb_fdiv(m, a.m_ohw);
+        } else {
+          n_ = bb_fdiv(m, a.m_ohw);
+          const int rr = m - n_ * (a.OH * a.OW);
+          const int oy = bb_fdiv(rr, a.m_ow), ox = rr - oy * a.OW;
+          pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
+        }
+        float v = acc[i][j][r] * sc + sh;
+        if (a.res && co_ok) v += bf2f(a.res[pix * a.Cbuf + co]);
+        if (a.relu) v = fmaxf(v, 0.0f);
+        if (a.out && co < a.Cbuf) a.out[pix * a.Cbuf + co] = co_ok ? f2bf(v) : uint16_t(0);
+        if (a.out_cl && co < a.out_jp) a.out_cl[pix * a.out_jp + co] = co_ok ? v : 0.0f;
+        if (a.out_nchw && co_ok) {
+          const size_t hw = size_t(a.ROH) * a.ROW;
+          a.out_nchw[(size_t(n_) * a.Cout + co) * hw + (pix - size_t(n_) * hw)] = v;
+        }
+      }
+    }
+  }
+}
+
+// MaxPool2d(3, stride 2, padding 1) on NHWC bf16: one thread per (output pixel, 8-channel group).
+__global__ void __launch_bounds__(256)
+k_bb_maxpool(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
+  const long i = long(blockIdx.x) * 256 + threadIdx.x;
+  const int cg = C / 8;
+  if (i >= long(N) * OH * OW * cg) return;
+  const int g = int(i % cg);
+  long p = i / cg;
+  const int ox = int(p % OW);
+  p /= OW;
+  const int oy = int(p % OH), n = int(p / OH);
+  float m[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+      if (unsigned(iy) >= unsigned(H) || unsigned(ix) >= unsigned(W)) continue;
+      const Bf8 v = *reinterpret_cast<const Bf8*>(in + (size_t(n * H + iy) * W + ix) * C + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf2f(uint16_t(v.w[e >> 1] >> (16 * (e & 1)))));
+    }
+  Bf8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o.w[e] = uint32_t(f2bf(m[2 * e])) | (uint32_t(f2bf(m[2 * e + 1])) << 16);
+  *reinterpret_cast<Bf8*>(out + (size_t(n * OH + oy) * OW + ox) * C + g * 8) = o;
+}
+
+// Images NCHW fp32 [N][3][H][W] -> NHWC bf16 [N][H][W][8] (channels 3..7 zero).
+__global__ void __launch_bounds__(256)
+k_bb_input(const float* __restrict__ img, uint16_t* __restrict__ out, int N, int C, int H, int W) {
+  const long i = long(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= long(N) * H * W) return;
+  const long hw = long(H) * W;
+  const int n = int(i / hw);
+  const long p = i - n * hw;
+  Bf8 o{{0u, 0u, 0u, 0u}};
+  uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < C && c < 8; ++c) v[c] = f2bf(img[(size_t(n) * C + c) * hw + p]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o.w[e] = uint32_t(v[2 * e]) | (uint32_t(v[2 * e + 1]) << 16);
+  *reinterpret_cast<Bf8*>(out + size_t(i) * 8) = o;
+}
+
+// Weights -> [cls][Coutp][ntaps*Cinp] bf16.  Conv: weight [Cout][Cin][KH][KW], taps (kh, kw) row-major.
+// ConvTranspose(k4,s2,p1): weight [Cin][Cout][4][4]; class (py, px) uses taps (a, b) in {0,1}^2 with
+// kh = 1 - py + 2a ... see tap tables on the host: kh = khs[py][a], kw = khs[px][b].
+__global__ void __launch_bounds__(256)
+k_bb_pack_w(const float* __restrict__ w, int transposed, int cin, int cout, int cinp, int coutp, int kh, int kw,
+            uint16_t* __restrict__ dst) {
+  const int ncls = transposed ? 4 : 1;
+  const int ntaps = transposed ? 4 : kh * kw;
+  const int K = ntaps * cinp;
+  const long total = long(ncls) * coutp * K;
+  const long i = long(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int kk = int(i % K);
+  long r = i / K;
+  const int co = int(r % coutp), cls = int(r / coutp);
+  const int tap = kk / cinp, ci = kk - tap * cinp;
+  float v = 0.0f;
+  if (co < cout && ci < cin) {
+    if (!transposed) {
+      v = w[((size_t(co) * cin + ci) * kh + tap / kw) * kw + tap % kw];
+    } else {
+      const int py = cls >> 1, px = cls & 1, ta = tap >> 1, tb = tap & 1;
+      const int ky = py ? 2 * ta : 1 + 2 * ta;        // oy = 2y + py gathers input rows y + dy via kernel row ky
+      const int kx = px ? 2 * tb : 1 + 2 * tb;
+      v = w[((size_t(ci) * cout + co) * kh + ky) * kw + kx];
+    }
+  }
+  dst[i] = f2bf(v);
+}
+
+// conv bias + eval BatchNorm -> scale | shift (y = acc * scale + shift), each coutp
+__global__ void __launch_bounds__(256)
+k_bb_pack_epi(const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+              const float* __restrict__ mean, const float* __restrict__ var, float eps, int cout, int coutp,
+              float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= coutp) return;
+  float sc = 1.0f, sh = 0.0f;
+  if (i < cout) {
+    const float b = bias ? bias[i] : 0.0f;
+    if (gamma) {
+      sc = gamma[i] / sqrtf(var[i] + eps);
+      sh = beta[i] + (b - mean[i]) * sc;
+    } else {
+      sh = b;
+    }
+  } else {
+    sc = 0.0f;
+  }
+  dst[i] = sc;
+  dst[coutp + i] = sh;
+}
+
+static unsigned bb_magic(int d) { return d <= 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; }
+
+}  // namespace fvp
+
+using namespace fvp;
+
+extern "C" int fvp_bb_input(const float* images, uint16_t* nhwc8, int N, int C, int H, int W, fvp_stream_t s) {
+  FVP_REQUIRE(images && nhwc8 && N >= 0 && C >= 1 && C <= 8 && H > 0 && W > 0);
+  if (N == 0) return 0;
+  const long n = long(N) * H * W;
+  hipLaunchKernelGGL(k_bb_input, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(s), images, nhwc8, N, C, H, W);
+  return launch_status();
+}
+
+extern "C" int fvp_bb_pack(const float* weight, const float* bias, const float* bn_gamma, const float* bn_beta,
+                           const float* bn_mean, const float* bn_var, float eps, const FvpBbOp* op, uint16_t* wblob,
+                           float* eblob, fvp_stream_t s) {
+  FVP_REQUIRE(weight && op && wblob && eblob && (!bn_gamma || (bn_beta && bn_mean && bn_var)));
+  FVP_REQUIRE(op->kind == FVP_BB_CONV || op->kind == FVP_BB_DECONV);
+  const int tr = op->kind == FVP_BB_DECONV;
+  FVP_REQUIRE(!tr || (op->kh == 4 && op->kw == 4 && op->stride == 2 && op->pad == 1));
+  const int ntaps = tr ? 4 : op->kh * op->kw;
+  const long total = long(tr ? 4 : 1) * op->coutp * ntaps * op->cinp;
+  hipLaunchKernelGGL(k_bb_pack_w, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(s), weight, tr, op->cin,
+                     op->cout, op->cinp, op->coutp, op->kh, op->kw, wblob + op->w_off);
+  hipLaunchKernelGGL(k_bb_pack_epi, dim3(ceil_div(op->coutp, 256)), dim3(256), 0, as_stream(s), bias, bn_gamma, bn_beta,
+                     bn_mean, bn_var, eps, op->cout, op->coutp, eblob + op->e_off);
+  return launch_status();
+}
+
+static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s) {
+  const int M = a.N * a.OH * a.OW;
+  dim3 grid(ceil_div(M, 128), op.coutp / (op.coutp % 128 == 0 ? 128 : 64));
+  if (op.coutp % 128 == 0)
+    hipLaunchKernelGGL(k_bb_conv<128>, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_bb_conv<64>, grid, dim3(256), 0, s, a);
+  return launch_status();
+}
+
+extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs,
+                          int nbufs, int N, float* heat_cl, int heat_jp, float* heat_nchw, fvp_stream_t s) {
+  FVP_REQUIRE(ops && wblob && eblob && bufs && nops >= 0 && N >= 0);
+  if (N == 0) return 0;
+  double flops = 0.0;
+  for (int i = 0; i < nops; ++i)
+    if (ops[i].kind != FVP_BB_MAXPOOL)
+      flops += 2.0 * ops[i].cin * ops[i].cout * (ops[i].kind == FVP_BB_DECONV ? 4.0 : double(ops[i].kh * ops[i].kw)) *
+               ops[i].oh * ops[i].ow * N;
+  ProfScope ps(FVP_K_BACKBONE, as_stream(s), flops, nops);
+  for (int i = 0; i < nops; ++i) {
+    const FvpBbOp& op = ops[i];
+    FVP_REQUIRE(op.src >= 0 && op.src < nbufs && op.dst < nbufs && op.res < nbufs);
+    if (op.kind == FVP_BB_MAXPOOL) {
+      const long n = long(N) * op.oh * op.ow * (op.cinp / 8);
+      hipLaunchKernelGGL(k_bb_maxpool, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(s),
+                         (const uint16_t*)bufs[op.src], (uint16_t*)bufs[op.dst], N, op.h, op.w, op.cinp, op.oh, op.ow);
+      if (int rc = launch_status()) return rc;
+      continue;
+    }
+    FVP_REQUIRE(op.kind == FVP_BB_CONV || op.kind == FVP_BB_DECONV);
+    FVP_LIMIT(op.cinp >= 8 && (op.cinp & (op.cinp - 1)) == 0 && op.coutp % 64 == 0);
+    BbConvArgs a{};
+    a.in = (const uint16_t*)bufs[op.src];
+    a.out = op.dst >= 0 ? (uint16_t*)bufs[op.dst] : nullptr;
+    a.res = op.res >= 0 ? (const uint16_t*)bufs[op.res] : nullptr;
+    a.epi = eblob + op.e_off;
+    a.N = N;
+    a.H = op.h;
+    a.W = op.w;
+    a.Cinp = op.cinp;
+    a.cin_log2 = __builtin_ctz(unsigned(op.cinp));
+    a.Cout = op.cout;
+    a.Coutp = op.coutp;
+    a.Cbuf = op.cbuf;
+    a.ROH = op.oh;
+    a.ROW = op.ow;
+    a.relu = (op.flags & FVP_EPI_RELU) ? 1 : 0;
+    if (op.flags & FVP_BB_OUT_HEAT) {
+      FVP_REQUIRE((heat_cl && heat_jp >= op.cout) || heat_nchw);
+      a.out_cl = heat_cl;
+      a.out_jp = heat_jp;
+      a.out_nchw = heat_nchw;
+    }
+    if (op.kind == FVP_BB_CONV) {
+      FVP_LIMIT(op.kh * op.kw <= 64);
+      a.OH = op.oh;
+      a.OW = op.ow;
+      a.stride = op.stride;
+      a.os = 1;
+      a.ntaps = op.kh * op.kw;
+      for (int t = 0; t < a.ntaps; ++t) {
+        a.dy[t] = (signed char)(t / op.kw - op.pad);
+        a.dx[t] = (signed char)(t % op.kw - op.pad);
+      }
+      a.K = a.ntaps * op.cinp;
+      a.w = wblob + op.w_off;
+      a.m_ow = bb_magic(a.OW);
+      a.m_ohw = bb_magic(a.OH * a.OW);
+      if (int rc = bb_launch_conv(op, a, as_stream(s))) return rc;
+    } else {
+      // ConvTranspose(k4, s2, p1): output (2y + py, 2x + px) gathers input rows y + dy: py = 0 -> (ky 1, dy 0),
+      // (ky 3, dy -1); py = 1 -> (ky 0, dy +1), (ky 2, dy 0)
+      a.OH = op.h;
+      a.OW = op.w;
+      a.stride = 1;
+      a.os = 2;
+      a.ntaps = 4;
+      a.K = 4 * op.cinp;
+      a.m_ow = bb_magic(a.OW);
+      a.m_ohw = bb_magic(a.OH * a.OW);
+      for (int cls = 0; cls < 4; ++cls) {
+        a.py = cls >> 1;
+        a.px = cls & 1;
+        for (int t = 0; t < 4; ++t) {
+          const int ta = t >> 1, tb = t & 1;
+          a.dy[t] = (signed char)(a.py ? (ta ? 0 : 1) : (ta ? -1 : 0));
+          a.dx[t] = (signed char)(a.px ? (tb ? 0 : 1) : (tb ? -1 : 0));
+        }
+        a.w = wblob + op.w_off + size_t(cls) * op.coutp * a.K;
+        if (int rc = bb_launch_conv(op, a, as_stream(s))) return rc;
+      }
+    }
+  }
+  return 0;
+}

@@ -74,7 +74,7 @@ using namespace fvp;
 extern "C" int fvp_version(void) { return FVP_ABI_VERSION; }
 
 extern "C" int fvp_sizeof(int what) {
-  return what == 0 ? int(sizeof(FvpGeom)) : what == 1 ? int(sizeof(FvpConvOp)) : FVP_EINVAL;
+  return what == 0 ? int(sizeof(FvpGeom)) : what == 1 ? int(sizeof(FvpConvOp)) : what == 2 ? int(sizeof(FvpBbOp)) : FVP_EINVAL;
 }
 
 extern "C" const char* fvp_error_string(int code) {

@@ -198,3 +198,19 @@ def fill_state_dict(state_dict, seed=7, bbox_bias=None):
                 a = np.full(shape, bbox_bias)
         out[key] = torch.from_numpy(np.asarray(a, np.float32))
     return out
+
+
+def fill_backbone_state_dict(state_dict, seed=7):
+    """Seeded weights for a Pose-ResNet state_dict that keep activations O(1) through the 16
+    residual blocks in eval mode (the last BatchNorm of every block is damped, transposed convs are
+    scaled for their effective fan-in of Cin * 4)."""
+    out = fill_state_dict(state_dict, seed=seed)
+    for k in out:
+        if k.startswith("layer") and (k.endswith(".bn3.weight") or (k.endswith(".bn2.weight") and (k[:-10] + "bn3.weight") not in out)):
+            out[k] = out[k] * 0.3
+        if k.startswith("deconv_layers") and k.endswith(".weight") and out[k].dim() == 4:
+            cin, cout = out[k].shape[:2]
+            out[k] = out[k] * float(np.sqrt((cout * 16) / (cin * 4.0)))
+        if k == "final_layer.bias":
+            out[k] = torch.full_like(out[k], 0.05)
+    return out

@@ -234,6 +234,36 @@ int fvp_rasterise_heatmaps(const double* joints, const int32_t* num_people, int 
                            double feat_stride_x, double feat_stride_y, double sigma, float* heat_nchw,
                            float* heat_cl, int JP, fvp_stream_t s);
 
+/* ---- "next" row f-1: Pose-ResNet backbone in bf16 (lib/models/resnet.py:98-215) ------------------------
+ * Activations are NHWC bf16 (uint16 storage; the image input is padded to 8 channels), every conv /
+ * ConvTranspose(k4,s2,p1) is an implicit GEMM on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, eval
+ * BatchNorm folded into a per-cout scale / shift, residual add and ReLU in the epilogue.  The op flagged
+ * FVP_BB_OUT_HEAT (final_layer) writes fp32 heatmaps: channels-last [N][H*W][heat_jp] (what the projection
+ * kernels read) and / or NCHW [N][J][H][W] (the reference's layout). */
+enum { FVP_BB_CONV = 0, FVP_BB_MAXPOOL = 1, FVP_BB_DECONV = 2 };
+enum { FVP_BB_OUT_HEAT = 8 };   /* with FVP_EPI_RELU = 1 in `flags` */
+typedef struct FvpBbOp {
+  int32_t kind;
+  int32_t src, dst, res;      /* activation buffer ids (dst = -1 for the heatmap op, res = -1 if unused) */
+  int32_t cin, cinp;          /* true / stored input channels (cinp: power of two >= 8)                 */
+  int32_t cout, coutp, cbuf;  /* true couts, couts of the packed weights (multiple of 64), channels of dst */
+  int32_t kh, kw, stride, pad;
+  int32_t h, w, oh, ow;       /* input and output spatial size                                          */
+  int32_t flags;
+  int32_t w_off;              /* bf16 element offset of the packed weights in wblob                     */
+  int32_t e_off;              /* float offset of scale | shift (2 * coutp) in eblob                      */
+} FvpBbOp;
+/* images [N][C<=8][H][W] fp32 -> NHWC bf16 with 8 channels */
+int fvp_bb_input(const float* images, uint16_t* nhwc8, int N, int C, int H, int W, fvp_stream_t s);
+/* state_dict tensors of one conv (+ its BatchNorm, may be NULL) -> packed bf16 weights [cls][coutp][taps*cinp]
+ * and fp32 scale | shift (resnet.py conv / bn / deconv / final_layer modules) */
+int fvp_bb_pack(const float* weight, const float* bias, const float* bn_gamma, const float* bn_beta,
+                const float* bn_mean, const float* bn_var, float eps, const FvpBbOp* op, uint16_t* wblob,
+                float* eblob, fvp_stream_t s);
+/* run the op list on N images; bufs[i] = NHWC bf16 activation buffer i */
+int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs, int nbufs,
+               int N, float* heat_cl, int heat_jp, float* heat_nchw, fvp_stream_t s);
+
 /* ---- measurement hooks (bench.py roofline leg) -----------------------------------------------------
  * fvp_prof_enable(1): kernel classes are bracketed by hipEvents on the stream they are launched
  * on -- per launch for the projection / soft-argmax / small kernels, one pair per
@@ -243,7 +273,7 @@ int fvp_rasterise_heatmaps(const double* joints, const int32_t* num_people, int 
  * fvp_prof_read synchronises the events and returns accumulated milliseconds, launch count and
  * algorithmic FLOPs since the last reset. */
 enum { FVP_K_PROJECT_WHOLE = 0, FVP_K_PROJECT_TRIPLANE = 1, FVP_K_CONV = 2, FVP_K_SOFTARGMAX = 3,
-       FVP_K_OTHER = 4, FVP_K_CONV_WINO = 5, FVP_K_COUNT = 6 };
+       FVP_K_OTHER = 4, FVP_K_CONV_WINO = 5, FVP_K_BACKBONE = 6, FVP_K_COUNT = 7 };
 int fvp_prof_enable(int on);
 int fvp_prof_read(int cls, double* ms, int64_t* launches, double* flops);
 int fvp_prof_reset(void);

@@ -598,3 +598,70 @@ def input_heatmaps_from_pred2d(all_preds, resize_transform, image_size, heatmap_
                 preds[n][i, :2] = np.dot(t, new_pt)[:2]                    # utils/transforms.py:53-56
         out.append(torch.from_numpy(generate_input_heatmap(preds, image_size, heatmap_size, sigma)))
     return torch.stack(out, dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# "next" row f-1: Pose-ResNet backbone (lib/models/resnet.py:98-215), functional over a flat state_dict
+# --------------------------------------------------------------------------------------
+RESNET_SPEC = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
+               101: ("bottleneck", [3, 4, 23, 3]), 152: ("bottleneck", [3, 8, 36, 3])}
+
+
+def _q(t, bf16):
+    """bf16 storage emulation: round to bfloat16 (nearest even), keep computing in fp32."""
+    return t.bfloat16().float() if bf16 else t
+
+
+def _bn_affine(sd, key, eps=1e-5):
+    sc = sd[key + ".weight"] / torch.sqrt(sd[key + ".running_var"] + eps)
+    return sc, sd[key + ".bias"] - sd[key + ".running_mean"] * sc
+
+
+def pose_resnet(sd, x, num_layers=50, num_deconv=3, bf16=False):
+    """x [N,3,H,W] -> heatmaps [N,J,H/4,W/4].  ``bf16=True`` reproduces the numerics of the HIP
+    backbone up to summation order: weights and every stored activation rounded to bfloat16, fp32
+    accumulation, BatchNorm as one fp32 scale / shift after the conv (folded; the reference applies
+    F.batch_norm, identical in exact arithmetic), fp32 heatmaps."""
+    block, layers = RESNET_SPEC[num_layers]
+
+    def conv_bn(x, ckey, bnkey, stride=1, pad=0, relu=True, res=None, transposed=False, bias=None):
+        w = _q(sd[ckey + ".weight"], bf16)
+        if transposed:
+            y = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+        else:
+            y = F.conv2d(x, w, None, stride=stride, padding=pad)
+        if bnkey is not None:
+            sc, sh = _bn_affine(sd, bnkey)
+            if bias is not None:
+                sh = sh + bias * sc
+            y = y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        elif bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        if res is not None:
+            y = y + res
+        return F.relu(y) if relu else y
+
+    x = _q(x, bf16)
+    x = _q(conv_bn(x, "conv1", "bn1", stride=2, pad=3), bf16)                      # resnet.py:185-187
+    x = F.max_pool2d(x, 3, 2, 1)                                                   # :188
+    inplanes = 64
+    for li, (planes, nblocks) in enumerate(zip((64, 128, 256, 512), layers), start=1):
+        for b in range(nblocks):
+            pre = f"layer{li}.{b}"
+            stride = 2 if (b == 0 and li > 1) else 1
+            exp = 4 if block == "bottleneck" else 1
+            resid = x
+            if b == 0 and (stride != 1 or inplanes != planes * exp):                # :133-139
+                resid = _q(conv_bn(x, pre + ".downsample.0", pre + ".downsample.1", stride=stride, relu=False), bf16)
+            if block == "bottleneck":                                              # :76-95
+                h = _q(conv_bn(x, pre + ".conv1", pre + ".bn1"), bf16)
+                h = _q(conv_bn(h, pre + ".conv2", pre + ".bn2", stride=stride, pad=1), bf16)
+                x = _q(conv_bn(h, pre + ".conv3", pre + ".bn3", res=resid), bf16)
+            else:                                                                  # :37-54
+                h = _q(conv_bn(x, pre + ".conv1", pre + ".bn1", stride=stride, pad=1), bf16)
+                x = _q(conv_bn(h, pre + ".conv2", pre + ".bn2", pad=1, res=resid), bf16)
+            inplanes = planes * exp
+    for d in range(num_deconv):                                                    # :163-181
+        bias = sd.get(f"deconv_layers.{3 * d}.bias")
+        x = _q(conv_bn(x, f"deconv_layers.{3 * d}", f"deconv_layers.{3 * d + 1}", transposed=True, bias=bias), bf16)
+    return conv_bn(x, "final_layer", None, relu=False, bias=sd["final_layer.bias"])  # :197

@@ -159,6 +159,32 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k = 8*(l>>5) + e], B[k][j=l&31], 8 bf16 per lane and operand
+// (passed as four 32-bit words); D as the f32 32x32 form.  Products are exact in fp32; the
+// accumulation order of the hardware is not specified -- k-ascending fp32 adds here.
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(const uint32_t* a, const uint32_t* b, hipemu_f32x16 c) {
+  uint32_t all[2][64][4];                              // the exchange carries 4 words per lane: A, then B
+  hipemu::wave_exchange(a, 4, all[0]);
+  hipemu::wave_exchange_done();
+  hipemu::wave_exchange(b, 4, all[1]);
+  const int l = hipemu::cur->lane, col = l & 31, hi = l >> 5;
+  auto elem = [&](int lane, int which, int e) {
+    const uint32_t w = all[which][lane][e >> 1];
+    const uint32_t h = (e & 1) ? (w >> 16) : (w & 0xffffu);
+    const uint32_t u = h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) acc += elem(row + 32 * (k >> 3), 0, k & 7) * elem(col + 32 * (k >> 3), 1, k & 7);
+    c[r] = acc;
+  }
+  hipemu::wave_exchange_done();
+  return c;
+}
 
 // LDS-DMA: wave-uniform LDS base + lane * size, per-lane global source
 static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* l,

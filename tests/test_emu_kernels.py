@@ -154,3 +154,25 @@ def test_rasteriser_kernel_matches_reference_golden(emu_lib):
         V, _, H, W = g.shape
         assert np.array_equal(cl.numpy()[..., :J], g.reshape(V, J, H * W).transpose(0, 2, 1))
         assert not cl.numpy()[..., J:].any()
+
+
+def test_backbone_emulated_matches_bf16_oracle(emu_lib):
+    """The whole Pose-ResNet-50 through fvp_bb_run (emulated bf16 MFMA) on a 32x32 image: as close to
+    the fp32 evaluation as the oracle's bf16-emulating mode is (two bf16 evaluations with different
+    summation orders agree with each other only to the same ~1 %), both heatmap layouts identical."""
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    cfg = CFG.default_config()
+    cfg.DEVICE = "cpu"
+    m = RN.PoseResNet(cfg, _lib=emu_lib)
+    sd = S.fill_backbone_state_dict(m.state_dict(), seed=3)
+    m.load_state_dict(sd)
+    x = torch.from_numpy(np.random.default_rng(0).random((1, 3, 32, 32), dtype=np.float32))
+    y = m(x)
+    o32, o16 = O.pose_resnet(sd, x), O.pose_resnet(sd, x, bf16=True)
+    e_prod = float((y - o32).norm() / o32.norm())
+    e_orc = float((o16 - o32).norm() / o32.norm())
+    assert e_prod < 1.5 * e_orc + 1e-3, (e_prod, e_orc)
+    cl = m.forward_channels_last(x)
+    J = cfg.DATASET.NUM_JOINTS
+    assert torch.equal(cl[..., :J], y.reshape(1, J, -1).permute(0, 2, 1)) and not cl[..., J:].any()

@@ -312,3 +312,34 @@ def test_precomputed_heatmap_path_end_to_end_shelf():
     v = oc[0, :, 3] >= 0
     err = (fused[0].cpu()[v][..., :3] - of[0][v][..., :3]).norm(dim=-1).max().item()
     assert err < 5e-2, err
+
+
+@pytest.mark.gpu
+def test_backbone_bf16_vs_oracle_and_reference_golden():
+    """Pose-ResNet-50 on the GPU (fvp_bb_run, bf16 MFMA) on the golden's [2,3,96,128] batch: as close
+    to the reference's fp32 heatmaps as a bf16 evaluation gets (the oracle's bf16-emulating mode is
+    the yardstick), identical NCHW / channels-last outputs, and drop-in use as `backbone=` of the
+    voxel model."""
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import sys
+    sys.path.insert(0, sys_path)
+    from make_golden_backbone import WSEED, inputs
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    g = load_golden("backbone_r50")
+    cfg = CFG.default_config()
+    m = RN.get(cfg).to("cuda:0")
+    sd = S.fill_backbone_state_dict(m.state_dict(), seed=WSEED)
+    m.load_state_dict(sd)
+    x = inputs()
+    with torch.no_grad():
+        y = m(x.cuda())
+        cl = m.forward_channels_last(x.cuda())
+    ref = torch.from_numpy(g["heatmaps"])
+    o16 = O.pose_resnet(sd, x, bf16=True)
+    e_prod = float((y.cpu() - ref).norm() / ref.norm())
+    e_orc = float((o16 - ref).norm() / ref.norm())
+    assert e_prod < 1.5 * e_orc + 1e-3, (e_prod, e_orc)
+    J = cfg.DATASET.NUM_JOINTS
+    assert torch.equal(cl[..., :J], y.reshape(2, J, -1).permute(0, 2, 1)) and not cl[..., J:].any()
+    assert torch.equal(y, m(x.cuda()))                       # deterministic

@@ -105,3 +105,25 @@ def test_oracle_rasteriser_matches_reference_golden(case):
     hm = torch.stack(out).numpy()
     assert hm.dtype == np.float32 and hm.shape == g["heatmaps"].shape
     assert np.array_equal(hm, g["heatmaps"])
+
+
+# ---- "next" row f-1: Pose-ResNet-50 backbone ----------------------------------------------------------
+def test_oracle_backbone_matches_reference_golden():
+    """The functional restatement of resnet.py (BatchNorm folded to scale / shift) reproduces the
+    reference's heatmaps; its bf16-emulating mode stays within ~1 % of them; the product module has
+    the reference's state_dict keys."""
+    from make_golden_backbone import WSEED, inputs
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    g = load_golden("backbone_r50")
+    cfg = CFG.default_config()
+    cfg.DEVICE = "cpu"
+    m = RN.PoseResNet(cfg, _lib=object())
+    assert list(m.state_dict()) == list(g["keys"])
+    sd = S.fill_backbone_state_dict(m.state_dict(), seed=WSEED)
+    x = inputs()
+    y32 = O.pose_resnet(sd, x).numpy()
+    ref = g["heatmaps"]
+    np.testing.assert_allclose(y32, ref, rtol=0, atol=2e-4 * float(np.abs(ref).max()))
+    y16 = O.pose_resnet(sd, x, bf16=True).numpy()
+    assert np.linalg.norm(y16 - ref) / np.linalg.norm(ref) < 3e-2
