@@ -10,8 +10,8 @@
 //               store 32 consecutive channels of one pixel = 64 contiguous bytes of NHWC
 //
 // Workgroup = 4 waves (2 x 2), tile 128 pixels x 128 couts (64 for the 64-channel layers), k chunks
-// of 32 through two LDS buffers with an 80-byte row pitch (conflict-free b128 reads); the next
-// chunk's global loads are in flight while the current one is multiplied.  A per-launch tap table
+// of 64 through two LDS buffers with a 144-byte row pitch (conflict-free b128 reads); the next
+// chunk's global loads (branch-free, address-clamped) are in flight while the current one is multiplied.  A per-launch tap table
 // (dy, dx) covers strided convs and the four parity classes of ConvTranspose(k4, s2, p1) with the
 // same kernel; the last layer writes fp32 heatmaps directly in the channels-last layout the
 // projection kernels read (and / or NCHW, the reference's layout).
@@ -64,57 +64,75 @@ __device__ __forceinline__ int bb_fdiv(int x, unsigned magic) { return magic ? i
 
 template <int BN>
 __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
-  constexpr int BM = 128, BK = 32, LP = 40;           // LDS row pitch in bf16 (80 bytes)
+  constexpr int BM = 128, BK = 64, LP = BK + 8;       // LDS row pitch in bf16 (144 bytes: conflict-free b128 reads)
   constexpr int WN = BN / 2;                          // couts per wave: 64 or 32
   constexpr int NJ = WN / 32;                         // cout tiles per wave
-  __shared__ __attribute__((aligned(16))) uint16_t As[2][BM][LP];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN][LP];
+  constexpr int KS = BK / 16;                         // MFMA k steps per chunk
+  constexpr int NG = BK / 8;                          // 16-byte groups per row and chunk
+  constexpr int AU = BM * NG / 256;                   // A vectors per thread and chunk (4)
+  constexpr int BU = BN * NG / 256;                   // B vectors per thread and chunk (4 / 2)
+  HIP_DYNAMIC_SHARED(uint16_t, smem)                  // As[2][BM][LP] | Bs[2][BN][LP] | taps
+  uint16_t(*As)[BM][LP] = reinterpret_cast<uint16_t(*)[BM][LP]>(smem);
+  uint16_t(*Bs)[BN][LP] = reinterpret_cast<uint16_t(*)[BN][LP]>(smem + 2 * BM * LP);
+  signed char* tdy = reinterpret_cast<signed char*>(smem + 2 * BM * LP + 2 * BN * LP);
+  signed char* tdx = tdy + 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int M = a.N * a.OH * a.OW;
   const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
-
-  // ---- this thread's staging duty: one pixel row (two 8-wide k groups) and one weight row
-  const int arow = t >> 1, ag = (t & 1) * 2;
-  const int am = m0 + arow;
-  const bool arow_ok = am < M;
-  int an, aoy, aox;
-  {
-    const int mm = arow_ok ? am : 0;
-    an = bb_fdiv(mm, a.m_ohw);
-    const int r = mm - an * (a.OH * a.OW);
-    aoy = bb_fdiv(r, a.m_ow);
-    aox = r - aoy * a.OW;
+  if (t < 64) {
+    tdy[t] = a.dy[t];
+    tdx[t] = a.dx[t];
   }
-  const int brow = t >> 1;                            // < BN for BN = 128; for BN = 64 rows 64.. are skipped
-  const bool brow_ok = brow < BN;
-  const uint16_t* wrow = a.w + size_t(co0 + (brow_ok ? brow : 0)) * a.K;
 
-  Bf8 ra[2], rb[2];
-  auto gload = [&](int chunk) {
+  // ---- this thread's staging duty: AU groups of one pixel row pair ... every vector = (row, 8-wide k group)
+  // vector v = t + 256*u: row = v / NG, group = v % NG  (NG = 8: a wave reads 8 rows x 128 contiguous bytes)
+  int a_iy0[AU], a_ix0[AU], a_base[AU];               // per vector: o*stride per axis, image offset n*H*W
+  bool a_ok[AU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int kk = chunk * BK + (ag + u) * 8;
-      Bf8 v{{0u, 0u, 0u, 0u}};
-      if (kk < a.K && arow_ok) {
-        const int tap = kk >> a.cin_log2, c0 = kk & (a.Cinp - 1);
-        const int iy = aoy * a.stride + a.dy[tap], ix = aox * a.stride + a.dx[tap];
-        if (unsigned(iy) < unsigned(a.H) && unsigned(ix) < unsigned(a.W))
-          v = *reinterpret_cast<const Bf8*>(a.in + (size_t(an * a.H + iy) * a.W + ix) * a.Cinp + c0);
-      }
-      ra[u] = v;
-      Bf8 wv{{0u, 0u, 0u, 0u}};
-      if (kk < a.K && brow_ok) wv = *reinterpret_cast<const Bf8*>(wrow + kk);
-      rb[u] = wv;
+  for (int u = 0; u < AU; ++u) {
+    const int v = t + 256 * u, row = v / NG;
+    const int am = m0 + row;
+    a_ok[u] = am < M;
+    const int mm = a_ok[u] ? am : 0;
+    const int n = bb_fdiv(mm, a.m_ohw);
+    const int r = mm - n * (a.OH * a.OW);
+    const int oy = bb_fdiv(r, a.m_ow), ox = r - oy * a.OW;
+    a_iy0[u] = oy * a.stride;
+    a_ix0[u] = ox * a.stride;
+    a_base[u] = n * a.H * a.W;
+  }
+  const int ag = t % NG;                              // the same k group for all of this thread's vectors
+  __syncthreads();                                    // tap table visible
+
+  Bf8 ra[AU], rb[BU];
+  auto gload = [&](int chunk) {
+    const int kk = chunk * BK + ag * 8;
+    const bool k_ok = kk < a.K;
+    const int kc = k_ok ? kk : 0;
+    const int tap = kc >> a.cin_log2, c0 = kc & (a.Cinp - 1);
+    const int dy = tdy[tap], dx = tdx[tap];
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {                    // unconditional, address-clamped loads; masked afterwards
+      const int iy = a_iy0[u] + dy, ix = a_ix0[u] + dx;
+      const bool ok = k_ok && a_ok[u] && unsigned(iy) < unsigned(a.H) && unsigned(ix) < unsigned(a.W);
+      const size_t off = ok ? (size_t(a_base[u] + iy * a.W + ix) * a.Cinp + c0) : 0;
+      ra[u] = *reinterpret_cast<const Bf8*>(a.in + off);
+      if (!ok) ra[u] = Bf8{{0u, 0u, 0u, 0u}};
+    }
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const int row = (t + 256 * u) / NG;
+      rb[u] = *reinterpret_cast<const Bf8*>(a.w + size_t(co0 + row) * a.K + kc);
+      if (!k_ok) rb[u] = Bf8{{0u, 0u, 0u, 0u}};
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      *reinterpret_cast<Bf8*>(&As[buf][arow][(ag + u) * 8]) = ra[u];
-      if (brow_ok) *reinterpret_cast<Bf8*>(&Bs[buf][brow][(ag + u) * 8]) = rb[u];
-    }
+    for (int u = 0; u < AU; ++u) *reinterpret_cast<Bf8*>(&As[buf][(t + 256 * u) / NG][ag * 8]) = ra[u];
+#pragma unroll
+    for (int u = 0; u < BU; ++u) *reinterpret_cast<Bf8*>(&Bs[buf][(t + 256 * u) / NG][ag * 8]) = rb[u];
   };
 
   f32x16 acc[2][NJ];
@@ -133,7 +151,7 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
     const int buf = c & 1;
     if (c + 1 < nchunks) gload(c + 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       Bf8 fa[2], fb[NJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const Bf8*>(&As[buf][wm * 64 + i * 32 + l31][ks * 16 + 8 * half]);
@@ -148,9 +166,73 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: BN scale / shift, residual, ReLU; NHWC bf16 (or fp32 heatmaps for the last layer)
+  // ---- epilogue: BN scale / shift, residual, ReLU
   const float* scale = a.epi;
   const float* shift = a.epi + a.Coutp;
+  if (a.out && !a.out_cl && !a.out_nchw && (a.Cbuf & 7) == 0) {
+    // bf16 NHWC output: the wave's 64 x WN tile goes through LDS as fp32 (row pitch WN + 4) so that a lane
+    // ends up with 8 consecutive channels of one pixel: 16-byte residual loads and 16-byte stores.
+    constexpr int EP = WN + 4;
+    float* et = reinterpret_cast<float*>(smem) + wave * (64 * EP);      // 17 KB per wave, inside the A/B buffers
+    __syncthreads();                                                   // every wave is done with As / Bs
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = j * 32 + l31;
+      const float sc = scale[co0 + wn * WN + col], sh = shift[co0 + wn * WN + col];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP + col] = acc[i][j][r] * sc + sh;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                 // own LDS writes landed (wave-private tile)
+    __builtin_amdgcn_wave_barrier();
+    constexpr int GPR = WN / 8;                                         // 8-channel groups per row
+    constexpr int NV = 64 * GPR / 64;                                   // vectors per lane
+    size_t pixv[NV];
+    bool okv[NV];
+    Bf8 resv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {                                     // unconditional, clamped residual loads first
+      const int idx = lane + 64 * v, row = idx / GPR, g = idx % GPR;
+      const int m = m0 + wm * 64 + row;
+      const int co = co0 + wn * WN + g * 8;
+      okv[v] = m < M && co < a.Cbuf;
+      const int mm = okv[v] ? m : 0;
+      size_t pix = size_t(mm);
+      if (a.os != 1) {
+        const int n_ = bb_fdiv(mm, a.m_ohw);
+        const int rr = mm - n_ * (a.OH * a.OW);
+        const int oy = bb_fdiv(rr, a.m_ow), ox = rr - oy * a.OW;
+        pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
+      }
+      pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
+      if (a.res) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = lane + 64 * v, row = idx / GPR, g = idx % GPR;
+      const float4 lo = *reinterpret_cast<const float4*>(et + row * EP + g * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(et + row * EP + g * 8 + 4);
+      float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      Bf8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v0 = x[2 * e], v1 = x[2 * e + 1];
+        if (a.res) {
+          v0 += bf2f(uint16_t(resv[v].w[e] & 0xffffu));
+          v1 += bf2f(uint16_t(resv[v].w[e] >> 16));
+        }
+        if (a.relu) {
+          v0 = fmaxf(v0, 0.0f);
+          v1 = fmaxf(v1, 0.0f);
+        }
+        o.w[e] = uint32_t(f2bf(v0)) | (uint32_t(f2bf(v1)) << 16);
+      }
+      if (okv[v]) *reinterpret_cast<Bf8*>(a.out + pixv[v]) = o;
+    }
+    return;
+  }
+  // fp32 heatmaps of the last layer / odd channel counts (small): element-wise stores
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int co = co0 + wn * WN + j * 32 + l31;
@@ -162,17 +244,8 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m >= M) continue;
-        size_t pix;                                    // pixel index in the real output tensor
-        int n_ = 0;
-        if (a.os == 1) {
-          pix = size_t(m);
-          if (a.out_nchw) n_ = bb_fdiv(m, a.m_ohw);
-        } else {
-          n_ = bb_fdiv(m, a.m_ohw);
-          const int rr = m - n_ * (a.OH * a.OW);
-          const int oy = bb_fdiv(rr, a.m_ow), ox = rr - oy * a.OW;
-          pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
-        }
+        const int n_ = bb_fdiv(m, a.m_ohw);
+        const size_t pix = size_t(m);                  // the heatmap layer is a plain 1x1 conv (os = 1)
         float v = acc[i][j][r] * sc + sh;
         if (a.res && co_ok) v += bf2f(a.res[pix * a.Cbuf + co]);
         if (a.relu) v = fmaxf(v, 0.0f);
@@ -314,14 +387,25 @@ extern "C" int fvp_bb_pack(const float* weight, const float* bias, const float* 
   return launch_status();
 }
 
+template <int BN>
+static int bb_launch(const BbConvArgs& a, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = (2 * 128 * 72 + 2 * BN * 72) * sizeof(uint16_t) + 128;
+  static bool attr = false;
+  auto k = &k_bb_conv<BN>;
+  if (!attr && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return int(e);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  return launch_status();
+}
+
 static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s) {
   const int M = a.N * a.OH * a.OW;
-  dim3 grid(ceil_div(M, 128), op.coutp / (op.coutp % 128 == 0 ? 128 : 64));
-  if (op.coutp % 128 == 0)
-    hipLaunchKernelGGL(k_bb_conv<128>, grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(k_bb_conv<64>, grid, dim3(256), 0, s, a);
-  return launch_status();
+  const bool wide = op.coutp % 128 == 0;
+  dim3 grid(ceil_div(M, 128), op.coutp / (wide ? 128 : 64));
+  return wide ? bb_launch<128>(a, grid, s) : bb_launch<64>(a, grid, s);
 }
 
 extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs,

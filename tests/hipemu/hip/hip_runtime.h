@@ -159,6 +159,14 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+// lanes of a wave run in lock-step on the hardware; the emulator's fibers do not, so code that passes
+// data between lanes of one wave through LDS marks the hand-over with a wave barrier
+static inline void hipemu_wave_sync() {
+  uint32_t mine[1] = {0}, all[64][4];
+  hipemu::wave_exchange(mine, 1, all);
+  hipemu::wave_exchange_done();
+}
+#define __builtin_amdgcn_wave_barrier() hipemu_wave_sync()
 // v_mfma_f32_32x32x16_bf16: A[i=l&31][k = 8*(l>>5) + e], B[k][j=l&31], 8 bf16 per lane and operand
 // (passed as four 32-bit words); D as the f32 32x32 form.  Products are exact in fp32; the
 // accumulation order of the hardware is not specified -- k-ascending fp32 adds here.

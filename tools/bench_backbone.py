@@ -14,12 +14,47 @@ from faster_voxelpose_amd.core import config as CFG  # noqa: E402
 from faster_voxelpose_amd.models import resnet as RN  # noqa: E402
 
 
+def per_op(m, x, a):
+    import ctypes as C
+    from faster_voxelpose_amd import _capi as capi
+    N, _, H, W = x.shape
+    plan = m._plan(H, W)
+    bufs = []
+    for name in plan["names"]:
+        c, h, w = plan["shapes"][name]
+        bufs.append(torch.randn((N, h, w, c), device="cuda").bfloat16())
+    arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+    J = m.num_joints
+    cl = torch.empty((N, plan["out_hw"][0] * plan["out_hw"][1], 16), device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tot = 0.0
+    for i, op in enumerate(plan["ops"]):
+        one = (capi.FvpBbOp * 1)(op)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(4):
+            if it == 1:
+                e0.record()
+            rc = m.lib.fvp_bb_run(one, 1, C.c_void_p(m._wblob.data_ptr()), C.c_void_p(m._eblob.data_ptr()), arr, len(bufs), N,
+                                  C.c_void_p(cl.data_ptr()), 16, None, s)
+            assert rc == 0, rc
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 3
+        tot += us
+        fl = 0.0 if op.kind == 1 else 2.0 * op.cin * op.cout * (4 if op.kind == 2 else op.kh * op.kw) * op.oh * op.ow * N
+        by = 2.0 * N * (op.cinp * op.h * op.w + op.cout * op.oh * op.ow * (2 if op.res >= 0 else 1))
+        print(f"  op{i:2d} kind {op.kind} {op.cin:4d}->{op.cout:4d} k{op.kh} s{op.stride} @{op.h}x{op.w}  {us:8.1f} us  "
+              f"{fl / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s")
+    print(f"  total {tot / 1e3:.2f} ms")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=10)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--h", type=int, default=512)
     ap.add_argument("--w", type=int, default=960)
+    ap.add_argument("--per-op", action="store_true")
     a = ap.parse_args()
     cfg = CFG.default_config()
     m = RN.get(cfg).to("cuda:0")
@@ -35,6 +70,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
+    if a.per_op:
+        per_op(m, x, a)
     plan = m._plan(a.h, a.w)
     fl = 0.0
     for op in plan["ops"]:
