@@ -86,6 +86,9 @@ def main():
                          "detection stage of one batch overlaps the joint stage of the previous one")
     ap.add_argument("--prof-steps", type=int, default=5,
                     help="extra single-stream steps after the timed region with the per-class HIP-event timers on")
+    ap.add_argument("--backbone", action="store_true",
+                    help="end-to-end variant (BASELINE configs[4] shape): the step starts from 5 x [3,512,960] "
+                         "images per frame and runs the bf16 Pose-ResNet-50 backbone in front of the voxel path")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (per-kernel event timing is then unavailable)")
     args = ap.parse_args()
@@ -119,6 +122,16 @@ def main():
     nstreams = max(1, args.streams)
     pipe = FV.PipelinedForward(model, depth=nstreams) if nstreams > 1 else None
 
+    views = bb = None
+    if args.backbone:
+        from faster_voxelpose_amd.core import config as CFG
+        from faster_voxelpose_amd.models import resnet as RN
+        bb = RN.get(CFG.default_config()).to(dev)
+        bb.load_state_dict(S.fill_backbone_state_dict(bb.state_dict(), seed=3))
+        Wi, Hi = cfg.DATASET.IMAGE_SIZE
+        views = torch.rand(B, cfg.DATASET.CAMERA_NUM, 3, Hi, Wi, device=dev)
+        args.no_prof = True
+
     graphed = None
     if args.graph:
         args.no_prof = True
@@ -128,13 +141,14 @@ def main():
         if graphed is not None:
             fused = graphed(heat)[0]
         elif pipe is not None and pipelined:
-            (fused, planes, centers, _, _), ev = pipe.submit(meta=meta, input_heatmaps=heat, cameras=cams,
-                                                             resize_transform=rt)
+            kw = dict(backbone=bb, views=views) if bb is not None else dict(input_heatmaps=heat)
+            (fused, planes, centers, _, _), ev = pipe.submit(meta=meta, cameras=cams, resize_transform=rt, **kw)
             if world == 1:
                 return fused                     # consumed after the final synchronize
             ev.wait()                            # the gather runs on the current stream
         else:
-            fused, planes, centers, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+            kw = dict(backbone=bb, views=views) if bb is not None else dict(input_heatmaps=heat)
+            fused, planes, centers, _, _ = model(meta=meta, cameras=cams, resize_transform=rt, **kw)
         return gather_results(fused, world)
 
     with torch.no_grad():
@@ -245,7 +259,9 @@ def main():
                                    "seeded random weights", "frames_per_gpu_per_step": B,
                        "parallelism": f"frame-sharded dp{world}, all_gather of results",
                        "launch": "hipGraph replay" if args.graph else "eager (ctypes launches on the current stream)",
-                       "batches_in_flight": nstreams},
+                       "batches_in_flight": nstreams,
+                       "input": ("5 x [3,512,960] images per frame -> bf16 Pose-ResNet-50 -> voxel path" if args.backbone
+                                 else "heatmaps resident in HBM")},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }
         print(json.dumps(line))

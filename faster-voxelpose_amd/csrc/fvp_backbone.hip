@@ -56,11 +56,17 @@ struct BbConvArgs {
   int Cout, Coutp;
   int stride, os, py, px; // input pixel = o*stride + d ; output pixel = o*os + p
   int ntaps, K, relu, out_jp;
-  unsigned m_ow, m_ohw;   // fdiv magics: OW, OH*OW
   signed char dy[64], dx[64];
 };
 
-__device__ __forceinline__ int bb_fdiv(int x, unsigned magic) { return magic ? int(__umulhi(unsigned(x), magic)) : x; }
+// pixel index -> (image, row, col).  Plain integer division: the operand reaches N*OH*OW (millions), far
+// beyond the exact range of a 32-bit reciprocal multiply, and the decode runs a handful of times per thread.
+__device__ __forceinline__ void bb_decode(int m, int OW, int OHW, int& n, int& oy, int& ox) {
+  n = m / OHW;
+  const int r = m - n * OHW;
+  oy = r / OW;
+  ox = r - oy * OW;
+}
 
 template <int BN>
 __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
@@ -96,9 +102,8 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
     const int am = m0 + row;
     a_ok[u] = am < M;
     const int mm = a_ok[u] ? am : 0;
-    const int n = bb_fdiv(mm, a.m_ohw);
-    const int r = mm - n * (a.OH * a.OW);
-    const int oy = bb_fdiv(r, a.m_ow), ox = r - oy * a.OW;
+    int n, oy, ox;
+    bb_decode(mm, a.OW, a.OH * a.OW, n, oy, ox);
     a_iy0[u] = oy * a.stride;
     a_ix0[u] = ox * a.stride;
     a_base[u] = n * a.H * a.W;
@@ -200,9 +205,8 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
       const int mm = okv[v] ? m : 0;
       size_t pix = size_t(mm);
       if (a.os != 1) {
-        const int n_ = bb_fdiv(mm, a.m_ohw);
-        const int rr = mm - n_ * (a.OH * a.OW);
-        const int oy = bb_fdiv(rr, a.m_ow), ox = rr - oy * a.OW;
+        int n_, oy, ox;
+        bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
         pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
       }
       pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m >= M) continue;
-        const int n_ = bb_fdiv(m, a.m_ohw);
+        const int n_ = m / (a.OH * a.OW);
         const size_t pix = size_t(m);                  // the heatmap layer is a plain 1x1 conv (os = 1)
         float v = acc[i][j][r] * sc + sh;
         if (a.res && co_ok) v += bf2f(a.res[pix * a.Cbuf + co]);
@@ -357,8 +361,6 @@ k_bb_pack_epi(const float* __restrict__ bias, const float* __restrict__ gamma, c
   dst[coutp + i] = sh;
 }
 
-static unsigned bb_magic(int d) { return d <= 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; }
-
 }  // namespace fvp
 
 using namespace fvp;
@@ -465,8 +467,6 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       }
       a.K = a.ntaps * op.cinp;
       a.w = wblob + op.w_off;
-      a.m_ow = bb_magic(a.OW);
-      a.m_ohw = bb_magic(a.OH * a.OW);
       if (int rc = bb_launch_conv(op, a, as_stream(s))) return rc;
     } else {
       // ConvTranspose(k4, s2, p1): output (2y + py, 2x + px) gathers input rows y + dy: py = 0 -> (ky 1, dy 0),
@@ -477,8 +477,6 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       a.os = 2;
       a.ntaps = 4;
       a.K = 4 * op.cinp;
-      a.m_ow = bb_magic(a.OW);
-      a.m_ohw = bb_magic(a.OH * a.OW);
       for (int cls = 0; cls < 4; ++cls) {
         a.py = cls >> 1;
         a.px = cls & 1;

@@ -173,15 +173,26 @@ class HotPath:
         self._check_tensor(heatmaps, "heatmaps")
         heatmaps = heatmaps.contiguous()
         key = (heatmaps.data_ptr(), heatmaps._version, tuple(heatmaps.shape))
-        if not reuse or key != self._heat_key:
+        if not (reuse or self.__dict__.get("_adopted")) or key != self._heat_key:
+            self._adopted = False
             B, V = heatmaps.shape[:2]
             out = self.scratch("heat_cl", (B, V, self.H, self.W, self.JP))
             self._call("fvp_heatmaps_to_cl", _ptr(heatmaps), _ptr(out), B, C.byref(g), self.stream())
             self._heat_cl, self._heat_key = out, key
         return self._heat_cl
 
+    def adopt_staging(self, heatmaps, heat_cl):
+        """The producer of the heatmaps (the bf16 backbone) already wrote the channels-last copy
+        [B,V,H*W,JP]: use it for the next forward over exactly this ``heatmaps`` tensor."""
+        B, V = heatmaps.shape[:2]
+        assert heat_cl.is_contiguous() and heat_cl.numel() == B * V * self.H * self.W * self.JP
+        self._heat_cl = heat_cl.view(B, V, self.H, self.W, self.JP)
+        self._heat_key = (heatmaps.data_ptr(), heatmaps._version, tuple(heatmaps.shape))
+        self._adopted = True
+
     def invalidate_staging(self):
         self._heat_key = None
+        self._adopted = False
 
     def scratch(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)

@@ -35,9 +35,18 @@ class FasterVoxelPoseNet(nn.Module):
             raise NotImplementedError("only the inference branch of FasterVoxelPoseNet.forward is implemented "
                                       "(call model.eval()); training losses are outside the hot path")
         if views is not None:
-            # per-view backbone passes, as the reference (:36-38); the backbone is a separate module
-            num_views = views.shape[1]
-            input_heatmaps = torch.stack([backbone(views[:, c]) for c in range(num_views)], dim=1)
+            if hasattr(backbone, "_run"):
+                # bf16 HIP backbone (models/resnet.py): all B*V views in one pass; it writes the heatmaps as
+                # NCHW (returned, like the reference) and in the channels-last layout the projection reads
+                B, V = views.shape[:2]
+                nchw, cl = backbone._run(views.flatten(0, 1), True, True)
+                input_heatmaps = nchw.view(B, V, *nchw.shape[1:])
+                if cl.shape[-1] == self.engine.JP:
+                    self.engine.adopt_staging(input_heatmaps, cl)
+            else:
+                # per-view backbone passes, as the reference (:36-38); any torch module
+                num_views = views.shape[1]
+                input_heatmaps = torch.stack([backbone(views[:, c]) for c in range(num_views)], dim=1)
         _, _, proposal_centers, _ = self.pose_net(input_heatmaps, meta, cameras, resize_transform)
         mask = proposal_centers[:, :, 3] >= 0
         fused_poses, plane_poses = self.joint_net.forward5(meta, input_heatmaps, proposal_centers, mask, cameras,

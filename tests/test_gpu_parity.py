@@ -343,3 +343,54 @@ def test_backbone_bf16_vs_oracle_and_reference_golden():
     J = cfg.DATASET.NUM_JOINTS
     assert torch.equal(cl[..., :J], y.reshape(2, J, -1).permute(0, 2, 1)) and not cl[..., J:].any()
     assert torch.equal(y, m(x.cuda()))                       # deterministic
+
+
+@pytest.mark.gpu
+def test_end_to_end_images_to_joints_config5_shape():
+    """BASELINE configs[4] shape in miniature: images -> bf16 backbone -> voxel pipeline in one forward
+    (`views=` + `backbone=`, like run/validate.py with TEST_HEATMAP_SRC = 'image').  The heatmaps the model
+    returns equal a standalone backbone call; the joints equal a forward on those heatmaps (the adopted
+    channels-last copy and the restaged one are the same data)."""
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import faster_voxelpose as FV, resnet as RN
+    cfg = S.make_cfg("panoptic", device="cuda:0", min_score=-1.0)
+    cams, seq = S.load_cameras("panoptic")
+    rt = S.resize_transform(cfg).cuda()
+    model = FV.get(cfg).to("cuda:0")
+    model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
+    bcfg = CFG.default_config()
+    bb = RN.get(bcfg).to("cuda:0")
+    bb.load_state_dict(S.fill_backbone_state_dict(bb.state_dict(), seed=3))
+    W, H = cfg.DATASET.IMAGE_SIZE
+    views = torch.rand(1, 5, 3, H, W, device="cuda")
+    meta = {"seq": [seq]}
+    with torch.no_grad():
+        fused, planes, centers, heat, _ = model(backbone=bb, views=views, meta=meta, cameras=cams, resize_transform=rt)
+        heat2 = bb(views[0])
+        assert heat.shape == (1, 5, cfg.DATASET.NUM_JOINTS, H // 4, W // 4) and torch.equal(heat[0], heat2)
+        f2, p2, c2, _, _ = model(meta=meta, input_heatmaps=heat.clone(), cameras=cams, resize_transform=rt)
+    assert torch.equal(fused, f2) and torch.equal(centers, c2)
+    assert torch.isfinite(fused).all()
+
+
+@pytest.mark.gpu
+def test_backbone_full_image_size_vs_oracle():
+    """Two 512 x 960 images (the Panoptic network-image size: pixel indices in the millions) against the
+    CPU oracle: same closeness to fp32 as the oracle's bf16-emulating evaluation."""
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    cfg = CFG.default_config()
+    m = RN.get(cfg).to("cuda:0")
+    sd = S.fill_backbone_state_dict(m.state_dict(), seed=3)
+    m.load_state_dict(sd)
+    x = torch.from_numpy(np.random.default_rng(9).random((2, 3, 512, 960), dtype=np.float32))
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+        o32 = O.pose_resnet(sd, x)
+        o16 = O.pose_resnet(sd, x, bf16=True)
+    e_prod = float((y - o32).norm() / o32.norm())
+    e_orc = float((o16 - o32).norm() / o32.norm())
+    assert e_prod < 1.5 * e_orc + 1e-3, (e_prod, e_orc)
+    # per-image agreement too (an indexing slip would hit the second image)
+    for n in range(2):
+        assert float((y[n] - o32[n]).norm() / o32[n].norm()) < 1.5 * e_orc + 2e-3
