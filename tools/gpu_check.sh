@@ -24,7 +24,20 @@ except Exception as e:
     print("bench sweep failed", e)
 PY
 done
+echo "== backbone (next row f-1)"
+timeout 600 python tools/bench_backbone.py --images 40 --iters 3 --per-op > "$out/backbone_per_op_${tag}.log" 2>&1; tail -2 "$out/backbone_per_op_${tag}.log"
+timeout 600 python bench.py --backbone --steps 8 --warmup 2 --streams 2 --no-cpu-baseline > "$out/bench_${tag}_e2e_b8_s2.json" 2>> "$out/bench_${tag}.err"
+timeout 600 python bench.py --backbone --steps 8 --warmup 2 --streams 1 --no-cpu-baseline > "$out/bench_${tag}_e2e_b8_s1.json" 2>> "$out/bench_${tag}.err"
+python - "$out/bench_${tag}_e2e_b8_s2.json" "$out/bench_${tag}_e2e_b8_s1.json" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.load(open(f)); print("end-to-end", d["config"]["input"][:40], "in flight", d["config"]["batches_in_flight"], "frames/s %.1f" % d["value"])
+    except Exception as e:
+        print("e2e bench failed", e)
+PY
 echo "== rocprofv3 kernel trace"
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-prof > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
 find "$out/prof_${tag}" -name "*kernel_stats*.csv" | head -1 | xargs -r head -40 | cut -c1-220
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_bb" -o trace -- python "$root/tools/bench_backbone.py" --images 40 --iters 3 > "$out/rocprof_${tag}_bb.log" 2>&1; echo "rocprof backbone rc=$?"
