@@ -10,8 +10,9 @@
 //               store 32 consecutive channels of one pixel = 64 contiguous bytes of NHWC
 //
 // Workgroup = 4 waves (2 x 2), tile 128 pixels x 128 couts (64 for the 64-channel layers), k chunks
-// of 64 through two LDS buffers with a 144-byte row pitch (conflict-free b128 reads); the next
-// chunk's global loads (branch-free, address-clamped) are in flight while the current one is multiplied.  A per-launch tap table
+// of 64 through one LDS buffer (37 KB: four workgroups per CU) with a 144-byte row pitch (conflict-free
+// b128 reads); the next chunk's global loads (branch-free, address-clamped) are in flight in registers
+// while the current one is multiplied.  A per-launch tap table
 // (dy, dx) covers strided convs and the four parity classes of ConvTranspose(k4, s2, p1) with the
 // same kernel; the last layer writes fp32 heatmaps directly in the channels-last layout the
 // projection kernels read (and / or NCHW, the reference's layout).
@@ -20,6 +21,10 @@
 #include <algorithm>
 
 #include "fvp_common.h"
+
+#ifndef FVP_BB_NBUF
+#define FVP_BB_NBUF 1
+#endif
 
 namespace fvp {
 
@@ -78,9 +83,10 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
   constexpr int AU = BM * NG / 256;                   // A vectors per thread and chunk (4)
   constexpr int BU = BN * NG / 256;                   // B vectors per thread and chunk (4 / 2)
   HIP_DYNAMIC_SHARED(uint16_t, smem)                  // As[2][BM][LP] | Bs[2][BN][LP] | taps
+  constexpr int NBUF = FVP_BB_NBUF;
   uint16_t(*As)[BM][LP] = reinterpret_cast<uint16_t(*)[BM][LP]>(smem);
-  uint16_t(*Bs)[BN][LP] = reinterpret_cast<uint16_t(*)[BN][LP]>(smem + 2 * BM * LP);
-  signed char* tdy = reinterpret_cast<signed char*>(smem + 2 * BM * LP + 2 * BN * LP);
+  uint16_t(*Bs)[BN][LP] = reinterpret_cast<uint16_t(*)[BN][LP]>(smem + NBUF * BM * LP);
+  signed char* tdy = reinterpret_cast<signed char*>(smem + NBUF * BM * LP + NBUF * BN * LP);
   signed char* tdx = tdy + 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -153,7 +159,7 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
   lstore(0);
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
+    const int buf = NBUF == 2 ? (c & 1) : 0;
     if (c + 1 < nchunks) gload(c + 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -167,7 +173,8 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
     }
-    if (c + 1 < nchunks) lstore(buf ^ 1);
+    if (NBUF == 1) __syncthreads();                    // single buffer: everyone done reading before the refill
+    if (c + 1 < nchunks) lstore(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -175,64 +182,64 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
   const float* scale = a.epi;
   const float* shift = a.epi + a.Coutp;
   if (a.out && !a.out_cl && !a.out_nchw && (a.Cbuf & 7) == 0) {
-    // bf16 NHWC output: the wave's 64 x WN tile goes through LDS as fp32 (row pitch WN + 4) so that a lane
-    // ends up with 8 consecutive channels of one pixel: 16-byte residual loads and 16-byte stores.
-    constexpr int EP = WN + 4;
-    float* et = reinterpret_cast<float*>(smem) + wave * (64 * EP);      // 17 KB per wave, inside the A/B buffers
+    // bf16 NHWC output: the wave's tile goes through LDS as fp32 so that a lane ends up with 8 consecutive
+    // channels of one pixel: 16-byte residual loads and 16-byte stores
+    // (32 couts at a time: 9 KB per wave, so the epilogue does not raise the kernel's LDS footprint)
+    constexpr int EP = 32 + 4;
+    float* et = reinterpret_cast<float*>(smem) + wave * (64 * EP);
     __syncthreads();                                                   // every wave is done with As / Bs
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int col = j * 32 + l31;
-      const float sc = scale[co0 + wn * WN + col], sh = shift[co0 + wn * WN + col];
+      const float sc = scale[co0 + wn * WN + j * 32 + l31], sh = shift[co0 + wn * WN + j * 32 + l31];
+      __builtin_amdgcn_wave_barrier();                                  // previous block's readers are done
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP + col] = acc[i][j][r] * sc + sh;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                                 // own LDS writes landed (wave-private tile)
-    __builtin_amdgcn_wave_barrier();
-    constexpr int GPR = WN / 8;                                         // 8-channel groups per row
-    constexpr int NV = 64 * GPR / 64;                                   // vectors per lane
-    size_t pixv[NV];
-    bool okv[NV];
-    Bf8 resv[NV];
+        for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP + l31] = acc[i][j][r] * sc + sh;
+      __builtin_amdgcn_s_waitcnt(0xc07f);                               // own LDS writes landed (wave-private tile)
+      __builtin_amdgcn_wave_barrier();
+      constexpr int NV = 64 * 4 / 64;                                   // 64 rows x 4 groups of 8 channels
+      size_t pixv[NV];
+      bool okv[NV];
+      Bf8 resv[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {                                     // unconditional, clamped residual loads first
-      const int idx = lane + 64 * v, row = idx / GPR, g = idx % GPR;
-      const int m = m0 + wm * 64 + row;
-      const int co = co0 + wn * WN + g * 8;
-      okv[v] = m < M && co < a.Cbuf;
-      const int mm = okv[v] ? m : 0;
-      size_t pix = size_t(mm);
-      if (a.os != 1) {
-        int n_, oy, ox;
-        bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
-        pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
-      }
-      pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
-      if (a.res) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v]);
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int idx = lane + 64 * v, row = idx / GPR, g = idx % GPR;
-      const float4 lo = *reinterpret_cast<const float4*>(et + row * EP + g * 8);
-      const float4 hi = *reinterpret_cast<const float4*>(et + row * EP + g * 8 + 4);
-      float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      Bf8 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v0 = x[2 * e], v1 = x[2 * e + 1];
-        if (a.res) {
-          v0 += bf2f(uint16_t(resv[v].w[e] & 0xffffu));
-          v1 += bf2f(uint16_t(resv[v].w[e] >> 16));
+      for (int v = 0; v < NV; ++v) {                                   // unconditional, clamped residual loads first
+        const int idx = lane + 64 * v, row = idx >> 2, g = idx & 3;
+        const int m = m0 + wm * 64 + row;
+        const int co = co0 + wn * WN + j * 32 + g * 8;
+        okv[v] = m < M && co < a.Cbuf;
+        const int mm = okv[v] ? m : 0;
+        size_t pix = size_t(mm);
+        if (a.os != 1) {
+          int n_, oy, ox;
+          bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
+          pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
         }
-        if (a.relu) {
-          v0 = fmaxf(v0, 0.0f);
-          v1 = fmaxf(v1, 0.0f);
-        }
-        o.w[e] = uint32_t(f2bf(v0)) | (uint32_t(f2bf(v1)) << 16);
+        pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
+        if (a.res) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v]);
       }
-      if (okv[v]) *reinterpret_cast<Bf8*>(a.out + pixv[v]) = o;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int idx = lane + 64 * v, row = idx >> 2, g = idx & 3;
+        const float4 lo = *reinterpret_cast<const float4*>(et + row * EP + g * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(et + row * EP + g * 8 + 4);
+        float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        Bf8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v0 = x[2 * e], v1 = x[2 * e + 1];
+          if (a.res) {
+            v0 += bf2f(uint16_t(resv[v].w[e] & 0xffffu));
+            v1 += bf2f(uint16_t(resv[v].w[e] >> 16));
+          }
+          if (a.relu) {
+            v0 = fmaxf(v0, 0.0f);
+            v1 = fmaxf(v1, 0.0f);
+          }
+          o.w[e] = uint32_t(f2bf(v0)) | (uint32_t(f2bf(v1)) << 16);
+        }
+        if (okv[v]) *reinterpret_cast<Bf8*>(a.out + pixv[v]) = o;
+      }
     }
     return;
   }
@@ -391,7 +398,9 @@ extern "C" int fvp_bb_pack(const float* weight, const float* bias, const float* 
 
 template <int BN>
 static int bb_launch(const BbConvArgs& a, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = (2 * 128 * 72 + 2 * BN * 72) * sizeof(uint16_t) + 128;
+  constexpr size_t lds_ab = (FVP_BB_NBUF * 128 * 72 + FVP_BB_NBUF * BN * 72) * sizeof(uint16_t) + 128;
+  constexpr size_t lds_ep = 4 * 64 * 36 * sizeof(float);               // epilogue tiles reuse the same memory
+  constexpr size_t lds = lds_ab > lds_ep ? lds_ab : lds_ep;
   static bool attr = false;
   auto k = &k_bb_conv<BN>;
   if (!attr && lds > 64 * 1024) {
