@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "fvp_common.h"
 
@@ -271,6 +272,167 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
   }
 }
 
+// Large-tile variant for layers with >= 256 couts and enough pixels: 8 waves, 256 pixels x 256 couts per
+// workgroup, 64 x 128 per wave (2 x 4 MFMA tiles = 128 accumulator registers, two waves per SIMD), so a k step
+// needs 6 ds_read_b128 for 8 MFMAs instead of 4 for 4 -- the 128 x 128 kernel is bound by LDS read bandwidth.
+// Both operand tiles are copied by the LDS-DMA (global_load_lds, 16 B per lane, no staging registers) into two
+// 72 KB slots: chunk c+1 streams in while chunk c is multiplied.  Row pitch 144 bytes = 9 DMA lanes per row, the
+// ninth reading a zero page; out-of-image taps, rows beyond M and k beyond K read the zero page as well.
+__global__ void __launch_bounds__(512, 2) k_bb_conv_big(BbConvArgs a, const uint16_t* __restrict__ zeros) {
+  constexpr int BM = 256, BN = 256, BK = 64, LP = BK + 8, QPR = 9;   // quads (16 B) per LDS row incl. the pad quad
+  constexpr int SLOT = (BM + BN) * LP;                               // bf16 elements per slot
+  constexpr int NITEM = BM * QPR;                                    // DMA items of one operand tile (2304)
+  constexpr int NR = (NITEM + 511) / 512;                            // DMA rounds per operand (5; the last one half full)
+  HIP_DYNAMIC_SHARED(uint16_t, smem)
+  signed char* tdy = reinterpret_cast<signed char*>(smem + 2 * SLOT);
+  signed char* tdx = tdy + 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = a.N * a.OH * a.OW;
+  const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+  if (t < 64) {
+    tdy[t] = a.dy[t];
+    tdx[t] = a.dx[t];
+  }
+  // ---- this lane's DMA items (fixed over the k loop): A item -> (pixel row, k group), B item -> (cout row, k group)
+  int a_iy0[NR], a_ix0[NR], a_base[NR], qv[NR];       // qv = k group 0..7, or -1: pad quad / item beyond the tile
+  bool a_ok[NR];                                      // pixel row inside M
+  int b_row[NR];                                      // element offset of the weight row
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int it = (wave + 8 * j) * 64 + lane;
+    const int row = it / QPR, q = it - row * QPR;
+    qv[j] = (it < NITEM && q < 8) ? q : -1;
+    a_ok[j] = false;
+    a_iy0[j] = a_ix0[j] = a_base[j] = 0;
+    b_row[j] = (co0 + (row < BN ? row : 0)) * a.K;    // packed weights are padded to Coutp rows
+    const int am = m0 + row;
+    if (qv[j] >= 0 && am < M) {
+      int n, oy, ox;
+      bb_decode(am, a.OW, a.OH * a.OW, n, oy, ox);
+      a_iy0[j] = oy * a.stride;
+      a_ix0[j] = ox * a.stride;
+      a_base[j] = n * a.H * a.W;
+      a_ok[j] = true;
+    }
+  }
+  __syncthreads();                                    // tap table visible
+  const int nchunks = (a.K + BK - 1) / BK;
+  auto stage = [&](int chunk, int slot) {
+    uint16_t* As = smem + slot * SLOT;
+    uint16_t* Bs = As + BM * LP;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int g = wave + 8 * j;
+      if (g * 64 < NITEM) {                           // wave-uniform: the last round is issued by half of the waves
+        const int kk = chunk * BK + (qv[j] < 0 ? 0 : qv[j]) * 8;
+        const bool k_ok = qv[j] >= 0 && kk < a.K;
+        const int kc = k_ok ? kk : 0;
+        const int tap = kc >> a.cin_log2, c0 = kc & (a.Cinp - 1);
+        const int iy = a_iy0[j] + tdy[tap], ix = a_ix0[j] + tdx[tap];
+        const bool ok = a_ok[j] && k_ok && unsigned(iy) < unsigned(a.H) && unsigned(ix) < unsigned(a.W);
+        const uint16_t* src = ok ? a.in + (size_t(a_base[j] + iy * a.W + ix) * a.Cinp + c0) : zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + g * 512), 16, 0, 0);
+        const uint16_t* wsrc = k_ok ? a.w + size_t(b_row[j]) + kc : zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
+                                         (__attribute__((address_space(3))) void*)(Bs + g * 512), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  stage(0, 0);
+  wait_vmcnt(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int slot = c & 1;
+    if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
+    const uint16_t* As = smem + slot * SLOT;
+    const uint16_t* Bs = As + BM * LP;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      Bf8 fa[2], fb[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const Bf8*>(As + (wm * 64 + i * 32 + l31) * LP + ks * 16 + 8 * half);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const Bf8*>(Bs + (wn * 128 + j * 32 + l31) * LP + ks * 16 + 8 * half);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
+    }
+    wait_vmcnt(0);                                    // this wave's share of chunk c+1 has landed
+    __syncthreads();                                  // ... everybody's; and everybody is done reading chunk c
+  }
+
+  // ---- epilogue: as in k_bb_conv (bf16 NHWC output through wave-private fp32 LDS tiles, 32 couts at a time)
+  const float* scale = a.epi;
+  const float* shift = a.epi + a.Coutp;
+  constexpr int EP = 32 + 4;
+  float* et = reinterpret_cast<float*>(smem) + wave * (64 * EP);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float sc = scale[co0 + wn * 128 + j * 32 + l31], sh = shift[co0 + wn * 128 + j * 32 + l31];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP + l31] = acc[i][j][r] * sc + sh;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    size_t pixv[4];
+    bool okv[4];
+    Bf8 resv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = lane + 64 * v, row = idx >> 2, g = idx & 3;
+      const int m = m0 + wm * 64 + row;
+      const int co = co0 + wn * 128 + j * 32 + g * 8;
+      okv[v] = m < M && co < a.Cbuf;
+      const int mm = okv[v] ? m : 0;
+      size_t pix = size_t(mm);
+      if (a.os != 1) {
+        int n_, oy, ox;
+        bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
+        pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
+      }
+      pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
+      if (a.res) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = lane + 64 * v, row = idx >> 2, g = idx & 3;
+      const float4 lo = *reinterpret_cast<const float4*>(et + row * EP + g * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(et + row * EP + g * 8 + 4);
+      float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      Bf8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v0 = x[2 * e], v1 = x[2 * e + 1];
+        if (a.res) {
+          v0 += bf2f(uint16_t(resv[v].w[e] & 0xffffu));
+          v1 += bf2f(uint16_t(resv[v].w[e] >> 16));
+        }
+        if (a.relu) {
+          v0 = fmaxf(v0, 0.0f);
+          v1 = fmaxf(v1, 0.0f);
+        }
+        o.w[e] = uint32_t(f2bf(v0)) | (uint32_t(f2bf(v1)) << 16);
+      }
+      if (okv[v]) *reinterpret_cast<Bf8*>(a.out + pixv[v]) = o;
+    }
+  }
+}
+
 // MaxPool2d(3, stride 2, padding 1) on NHWC bf16: one thread per (output pixel, 8-channel group).
 __global__ void __launch_bounds__(256)
 k_bb_maxpool(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
@@ -412,8 +574,24 @@ static int bb_launch(const BbConvArgs& a, dim3 grid, hipStream_t s) {
   return launch_status();
 }
 
-static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s) {
+static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const uint16_t* zeros) {
   const int M = a.N * a.OH * a.OW;
+  static const bool no_big = getenv("FVP_BB_NO_BIG") != nullptr;
+  static const long big_min = getenv("FVP_BB_BIG_MIN_TILES") ? atol(getenv("FVP_BB_BIG_MIN_TILES")) : 100;   // (tests: 1)
+  // large tiles whenever the layer has >= 256 couts (measured faster than the 128 x 128 kernel down to ~150
+  // workgroups: 685 vs 455 TFLOP/s on the 512->512 3x3 at 16x30) and the output is plain bf16 NHWC
+  if (!no_big && op.coutp % 256 == 0 && long(ceil_div(M, 256)) * (op.coutp / 256) >= big_min && a.out && !a.out_cl &&
+      !a.out_nchw && (a.Cbuf & 7) == 0 && size_t(op.coutp) * a.K < (1u << 30)) {
+    constexpr size_t lds = 2 * (256 + 256) * 72 * sizeof(uint16_t) + 128;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bb_conv_big), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (e != hipSuccess) return int(e);
+      attr = true;
+    }
+    hipLaunchKernelGGL(k_bb_conv_big, dim3(ceil_div(M, 256), op.coutp / 256), dim3(512), lds, s, a, zeros);
+    return launch_status();
+  }
   const bool wide = op.coutp % 128 == 0;
   dim3 grid(ceil_div(M, 128), op.coutp / (wide ? 128 : 64));
   return wide ? bb_launch<128>(a, grid, s) : bb_launch<64>(a, grid, s);
@@ -476,7 +654,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       }
       a.K = a.ntaps * op.cinp;
       a.w = wblob + op.w_off;
-      if (int rc = bb_launch_conv(op, a, as_stream(s))) return rc;
+      if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
     } else {
       // ConvTranspose(k4, s2, p1): output (2y + py, 2x + px) gathers input rows y + dy: py = 0 -> (ky 1, dy 0),
       // (ky 3, dy -1); py = 1 -> (ky 0, dy +1), (ky 2, dy 0)
@@ -495,7 +673,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
           a.dx[t] = (signed char)(a.px ? (tb ? 0 : 1) : (tb ? -1 : 0));
         }
         a.w = wblob + op.w_off + size_t(cls) * op.coutp * a.K;
-        if (int rc = bb_launch_conv(op, a, as_stream(s))) return rc;
+        if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
       }
     }
   }

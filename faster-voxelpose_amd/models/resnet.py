@@ -130,7 +130,7 @@ class PoseResNet(ParamTree):
         shapes = {"x": (8, H, W)}
         arr = (capi.FvpBbOp * len(self._convs))()
         names = ["x"]
-        w_off = e_off = 0
+        w_off, e_off = 0, 64                   # eblob[0:64] stays zero: the DMA's zero page
         for i, o in enumerate(self._convs):
             cin_buf, h, w = shapes[o["src"]]
             if o["kind"] == capi.BB_MAXPOOL:

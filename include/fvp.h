@@ -260,7 +260,8 @@ int fvp_bb_input(const float* images, uint16_t* nhwc8, int N, int C, int H, int 
 int fvp_bb_pack(const float* weight, const float* bias, const float* bn_gamma, const float* bn_beta,
                 const float* bn_mean, const float* bn_var, float eps, const FvpBbOp* op, uint16_t* wblob,
                 float* eblob, fvp_stream_t s);
-/* run the op list on N images; bufs[i] = NHWC bf16 activation buffer i */
+/* run the op list on N images; bufs[i] = NHWC bf16 activation buffer i.  The first 64 floats of eblob must be
+ * zero (e_off >= 64): the LDS-DMA of the large-tile kernel reads them for padding. */
 int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs, int nbufs,
                int N, float* heat_cl, int heat_jp, float* heat_nchw, fvp_stream_t s);
 

@@ -5,6 +5,8 @@ infrastructure; the product never loads it.)"""
 import ctypes as C
 import os
 
+os.environ.setdefault("FVP_BB_BIG_MIN_TILES", "1")   # emulated backbone runs exercise the large-tile kernel too
+
 import numpy as np
 import pytest
 import torch
