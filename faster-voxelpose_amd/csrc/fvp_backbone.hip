@@ -62,6 +62,7 @@ struct BbConvArgs {
   int Cout, Coutp;
   int stride, os, py, px; // input pixel = o*stride + d ; output pixel = o*os + p
   int ntaps, K, relu, out_jp;
+  int ncls;               // 1, or 4 parity classes of a transposed conv on blockIdx.z (tap tables / weights per class)
   signed char dy[64], dx[64];
 };
 
@@ -94,9 +95,12 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int M = a.N * a.OH * a.OW;
   const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+  const int cls = blockIdx.z;                          // parity class of a transposed conv (0 otherwise)
+  const int opy = a.ncls > 1 ? cls >> 1 : a.py, opx = a.ncls > 1 ? (cls & 1) : a.px;
+  const uint16_t* wcls = a.w + size_t(cls) * a.Coutp * a.K;
   if (t < 64) {
-    tdy[t] = a.dy[t];
-    tdx[t] = a.dx[t];
+    tdy[t] = a.dy[(t + cls * a.ntaps) & 63];
+    tdx[t] = a.dx[(t + cls * a.ntaps) & 63];
   }
 
   // ---- this thread's staging duty: AU groups of one pixel row pair ... every vector = (row, 8-wide k group)
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
 #pragma unroll
     for (int u = 0; u < BU; ++u) {
       const int row = (t + 256 * u) / NG;
-      rb[u] = *reinterpret_cast<const Bf8*>(a.w + size_t(co0 + row) * a.K + kc);
+      rb[u] = *reinterpret_cast<const Bf8*>(wcls + size_t(co0 + row) * a.K + kc);
       if (!k_ok) rb[u] = Bf8{{0u, 0u, 0u, 0u}};
     }
   };
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
         if (a.os != 1) {
           int n_, oy, ox;
           bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
-          pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
+          pix = (size_t(n_) * a.ROH + oy * a.os + opy) * a.ROW + ox * a.os + opx;
         }
         pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
         if (a.res) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v]);
@@ -291,9 +295,12 @@ __global__ void __launch_bounds__(512, 2) k_bb_conv_big(BbConvArgs a, const uint
   const int wm = wave >> 1, wn = wave & 1;
   const int M = a.N * a.OH * a.OW;
   const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+  const int cls = blockIdx.z;                          // parity class of a transposed conv (0 otherwise)
+  const int opy = a.ncls > 1 ? cls >> 1 : a.py, opx = a.ncls > 1 ? (cls & 1) : a.px;
+  const uint16_t* wcls = a.w + size_t(cls) * a.Coutp * a.K;
   if (t < 64) {
-    tdy[t] = a.dy[t];
-    tdx[t] = a.dx[t];
+    tdy[t] = a.dy[(t + cls * a.ntaps) & 63];
+    tdx[t] = a.dx[(t + cls * a.ntaps) & 63];
   }
   // ---- this lane's DMA items (fixed over the k loop): A item -> (pixel row, k group), B item -> (cout row, k group)
   int a_iy0[NR], a_ix0[NR], a_base[NR], qv[NR];       // qv = k group 0..7, or -1: pad quad / item beyond the tile
@@ -335,7 +342,7 @@ __global__ void __launch_bounds__(512, 2) k_bb_conv_big(BbConvArgs a, const uint
         const uint16_t* src = ok ? a.in + (size_t(a_base[j] + iy * a.W + ix) * a.Cinp + c0) : zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(As + g * 512), 16, 0, 0);
-        const uint16_t* wsrc = k_ok ? a.w + size_t(b_row[j]) + kc : zeros;
+        const uint16_t* wsrc = k_ok ? wcls + size_t(b_row[j]) + kc : zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
                                          (__attribute__((address_space(3))) void*)(Bs + g * 512), 16, 0, 0);
       }
@@ -403,7 +410,7 @@ __global__ void __launch_bounds__(512, 2) k_bb_conv_big(BbConvArgs a, const uint
       if (a.os != 1) {
         int n_, oy, ox;
         bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
-        pix = (size_t(n_) * a.ROH + oy * a.os + a.py) * a.ROW + ox * a.os + a.px;
+        pix = (size_t(n_) * a.ROH + oy * a.os + opy) * a.ROW + ox * a.os + opx;
       }
       pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
       if (a.res) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v]);
@@ -580,7 +587,7 @@ static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const 
   static const long big_min = getenv("FVP_BB_BIG_MIN_TILES") ? atol(getenv("FVP_BB_BIG_MIN_TILES")) : 100;   // (tests: 1)
   // large tiles whenever the layer has >= 256 couts (measured faster than the 128 x 128 kernel down to ~150
   // workgroups: 685 vs 455 TFLOP/s on the 512->512 3x3 at 16x30) and the output is plain bf16 NHWC
-  if (!no_big && op.coutp % 256 == 0 && long(ceil_div(M, 256)) * (op.coutp / 256) >= big_min && a.out && !a.out_cl &&
+  if (!no_big && op.coutp % 256 == 0 && long(ceil_div(M, 256)) * (op.coutp / 256) * a.ncls >= big_min && a.out && !a.out_cl &&
       !a.out_nchw && (a.Cbuf & 7) == 0 && size_t(op.coutp) * a.K < (1u << 30)) {
     constexpr size_t lds = 2 * (256 + 256) * 72 * sizeof(uint16_t) + 128;
     static bool attr = false;
@@ -589,11 +596,11 @@ static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const 
       if (e != hipSuccess) return int(e);
       attr = true;
     }
-    hipLaunchKernelGGL(k_bb_conv_big, dim3(ceil_div(M, 256), op.coutp / 256), dim3(512), lds, s, a, zeros);
+    hipLaunchKernelGGL(k_bb_conv_big, dim3(ceil_div(M, 256), op.coutp / 256, a.ncls), dim3(512), lds, s, a, zeros);
     return launch_status();
   }
   const bool wide = op.coutp % 128 == 0;
-  dim3 grid(ceil_div(M, 128), op.coutp / (wide ? 128 : 64));
+  dim3 grid(ceil_div(M, 128), op.coutp / (wide ? 128 : 64), a.ncls);
   return wide ? bb_launch<128>(a, grid, s) : bb_launch<64>(a, grid, s);
 }
 
@@ -653,6 +660,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
         a.dx[t] = (signed char)(t % op.kw - op.pad);
       }
       a.K = a.ntaps * op.cinp;
+      a.ncls = 1;
       a.w = wblob + op.w_off;
       if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
     } else {
@@ -664,17 +672,17 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       a.os = 2;
       a.ntaps = 4;
       a.K = 4 * op.cinp;
+      a.ncls = 4;                                       // one launch, the parity class on blockIdx.z
       for (int cls = 0; cls < 4; ++cls) {
-        a.py = cls >> 1;
-        a.px = cls & 1;
+        const int py = cls >> 1, px = cls & 1;
         for (int t = 0; t < 4; ++t) {
           const int ta = t >> 1, tb = t & 1;
-          a.dy[t] = (signed char)(a.py ? (ta ? 0 : 1) : (ta ? -1 : 0));
-          a.dx[t] = (signed char)(a.px ? (tb ? 0 : 1) : (tb ? -1 : 0));
+          a.dy[cls * 4 + t] = (signed char)(py ? (ta ? 0 : 1) : (ta ? -1 : 0));
+          a.dx[cls * 4 + t] = (signed char)(px ? (tb ? 0 : 1) : (tb ? -1 : 0));
         }
-        a.w = wblob + op.w_off + size_t(cls) * op.coutp * a.K;
-        if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
       }
+      a.w = wblob + op.w_off;
+      if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
     }
   }
   return 0;
