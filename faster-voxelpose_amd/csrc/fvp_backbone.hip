@@ -60,7 +60,8 @@ struct BbConvArgs {
   int OH, OW;             // grid the GEMM rows walk (output grid; input grid for a transposed-conv class)
   int ROH, ROW, Cbuf;     // real output tensor dims (NHWC, Cbuf channels)
   int Cout, Coutp;
-  int stride, os, py, px; // input pixel = o*stride + d ; output pixel = o*os + p
+  int stride, stride_x;   // input pixel = (oy*stride + dy, ox*stride_x + dx)
+  int os, py, px;         // output pixel = o*os + p
   int ntaps, K, relu, out_jp;
   int ncls;               // 1, or 4 parity classes of a transposed conv on blockIdx.z (tap tables / weights per class)
   signed char dy[64], dx[64];
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
     int n, oy, ox;
     bb_decode(mm, a.OW, a.OH * a.OW, n, oy, ox);
     a_iy0[u] = oy * a.stride;
-    a_ix0[u] = ox * a.stride;
+    a_ix0[u] = ox * a.stride_x;
     a_base[u] = n * a.H * a.W;
   }
   const int ag = t % NG;                              // the same k group for all of this thread's vectors
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(512, 2) k_bb_conv_big(BbConvArgs a, const uint
       int n, oy, ox;
       bb_decode(am, a.OW, a.OH * a.OW, n, oy, ox);
       a_iy0[j] = oy * a.stride;
-      a_ix0[j] = ox * a.stride;
+      a_ix0[j] = ox * a.stride_x;
       a_base[j] = n * a.H * a.W;
       a_ok[j] = true;
     }
@@ -468,20 +469,39 @@ k_bb_maxpool(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int N,
   *reinterpret_cast<Bf8*>(out + (size_t(n * OH + oy) * OW + ox) * C + g * 8) = o;
 }
 
-// Images NCHW fp32 [N][3][H][W] -> NHWC bf16 [N][H][W][8] (channels 3..7 zero).
+// Images NCHW fp32 [N][C<=4][H][W] -> NHWC bf16 with 4 channels per pixel (channel 3 zero for RGB).  Read as
+// [N][H][W/2][8] this is the input of the stem conv in its pixel-pair form (below).
 __global__ void __launch_bounds__(256)
 k_bb_input(const float* __restrict__ img, uint16_t* __restrict__ out, int N, int C, int H, int W) {
-  const long i = long(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= long(N) * H * W) return;
-  const long hw = long(H) * W;
-  const int n = int(i / hw);
-  const long p = i - n * hw;
-  Bf8 o{{0u, 0u, 0u, 0u}};
+  const long i = long(blockIdx.x) * 256 + threadIdx.x;     // one thread per pixel PAIR
+  const long hw = long(H) * W, hw2 = hw / 2;
+  if (i >= long(N) * hw2) return;
+  const int n = int(i / hw2);
+  const long p = (i - n * hw2) * 2;
   uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int c = 0; c < C && c < 8; ++c) v[c] = f2bf(img[(size_t(n) * C + c) * hw + p]);
+  for (int e = 0; e < 2; ++e)
+    for (int c = 0; c < C && c < 4; ++c) v[4 * e + c] = f2bf(img[(size_t(n) * C + c) * hw + p + e]);
+  Bf8 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o.w[e] = uint32_t(v[2 * e]) | (uint32_t(v[2 * e + 1]) << 16);
   *reinterpret_cast<Bf8*>(out + size_t(i) * 8) = o;
+}
+
+// Stem weights [Cout][Cin<=4][7][7] (stride 2, pad 3) in the pixel-pair form: the image is read as
+// [H][W/2] pixel pairs of 8 channels (2 pixels x 4), where the conv has stride (2, 1) and 7 x 4 taps:
+// pair tap p in 0..3 sits at pair offset p - 2 and holds kernel columns kw = 2p - 1 + e (e = pixel of the pair;
+// kw = -1 does not exist -> zero).  K = 7 * 4 * 8 = 224 instead of 7 * 7 * 8 = 392 with per-pixel padding.
+__global__ void __launch_bounds__(256)
+k_bb_pack_stem(const float* __restrict__ w, int cin, int cout, int coutp, uint16_t* __restrict__ dst) {
+  const int K = 7 * 4 * 8;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= coutp * K) return;
+  const int co = i / K, kk = i - co * K;
+  const int tap = kk >> 3, e = (kk >> 2) & 1, c = kk & 3;
+  const int kh = tap >> 2, p = tap & 3, kw = 2 * p - 1 + e;
+  float v = 0.0f;
+  if (co < cout && c < cin && kw >= 0) v = w[((size_t(co) * cin + c) * 7 + kh) * 7 + kw];
+  dst[i] = f2bf(v);
 }
 
 // Weights -> [cls][Coutp][ntaps*Cinp] bf16.  Conv: weight [Cout][Cin][KH][KW], taps (kh, kw) row-major.
@@ -544,7 +564,8 @@ using namespace fvp;
 extern "C" int fvp_bb_input(const float* images, uint16_t* nhwc8, int N, int C, int H, int W, fvp_stream_t s) {
   FVP_REQUIRE(images && nhwc8 && N >= 0 && C >= 1 && C <= 8 && H > 0 && W > 0);
   if (N == 0) return 0;
-  const long n = long(N) * H * W;
+  FVP_REQUIRE(W % 2 == 0 && C <= 4);
+  const long n = long(N) * H * W / 2;
   hipLaunchKernelGGL(k_bb_input, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(s), images, nhwc8, N, C, H, W);
   return launch_status();
 }
@@ -556,6 +577,14 @@ extern "C" int fvp_bb_pack(const float* weight, const float* bias, const float* 
   FVP_REQUIRE(op->kind == FVP_BB_CONV || op->kind == FVP_BB_DECONV);
   const int tr = op->kind == FVP_BB_DECONV;
   FVP_REQUIRE(!tr || (op->kh == 4 && op->kw == 4 && op->stride == 2 && op->pad == 1));
+  if (op->flags & FVP_BB_STEM) {
+    FVP_REQUIRE(!tr && op->kh == 7 && op->kw == 7 && op->stride == 2 && op->pad == 3 && op->cin <= 4 && op->cinp == 8);
+    hipLaunchKernelGGL(k_bb_pack_stem, dim3(ceil_div(op->coutp * 224, 256)), dim3(256), 0, as_stream(s), weight, op->cin,
+                       op->cout, op->coutp, wblob + op->w_off);
+    hipLaunchKernelGGL(k_bb_pack_epi, dim3(ceil_div(op->coutp, 256)), dim3(256), 0, as_stream(s), bias, bn_gamma, bn_beta,
+                       bn_mean, bn_var, eps, op->cout, op->coutp, eblob + op->e_off);
+    return launch_status();
+  }
   const int ntaps = tr ? 4 : op->kh * op->kw;
   const long total = long(tr ? 4 : 1) * op->coutp * ntaps * op->cinp;
   hipLaunchKernelGGL(k_bb_pack_w, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(s), weight, tr, op->cin,
@@ -652,12 +681,21 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       FVP_LIMIT(op.kh * op.kw <= 64);
       a.OH = op.oh;
       a.OW = op.ow;
-      a.stride = op.stride;
+      a.stride = a.stride_x = op.stride;
       a.os = 1;
       a.ntaps = op.kh * op.kw;
       for (int t = 0; t < a.ntaps; ++t) {
         a.dy[t] = (signed char)(t / op.kw - op.pad);
         a.dx[t] = (signed char)(t % op.kw - op.pad);
+      }
+      if (op.flags & FVP_BB_STEM) {                     // pixel-pair form: input [H][W/2] x 8 channels, 7 x 4 taps
+        a.W = op.w / 2;
+        a.stride_x = 1;
+        a.ntaps = 28;
+        for (int t = 0; t < 28; ++t) {
+          a.dy[t] = (signed char)(t / 4 - 3);
+          a.dx[t] = (signed char)(t % 4 - 2);
+        }
       }
       a.K = a.ntaps * op.cinp;
       a.ncls = 1;
@@ -668,7 +706,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       // (ky 3, dy -1); py = 1 -> (ky 0, dy +1), (ky 2, dy 0)
       a.OH = op.h;
       a.OW = op.w;
-      a.stride = 1;
+      a.stride = a.stride_x = 1;
       a.os = 2;
       a.ntaps = 4;
       a.K = 4 * op.cinp;

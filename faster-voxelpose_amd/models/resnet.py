@@ -64,7 +64,7 @@ class PoseResNet(ParamTree):
         self._conv("conv1", 3, 64, 7)
         self._bn("bn1", 64)
         ops.append(dict(kind=capi.BB_CONV, key="conv1", bn="bn1", cin=3, cout=64, k=7, stride=2, pad=3, relu=True,
-                        src="x", dst="c1"))
+                        src="x", dst="c1", stem=True))
         ops.append(dict(kind=capi.BB_MAXPOOL, cin=64, cout=64, src="c1", dst="p1"))
         cur, inplanes = "p1", 64
         exp = 4 if self.block == "bottleneck" else 1
@@ -127,7 +127,7 @@ class PoseResNet(ParamTree):
         """Op array + buffer shapes for an input of H x W (cached)."""
         if (H, W) in self._plans:
             return self._plans[(H, W)]
-        shapes = {"x": (8, H, W)}
+        shapes = {"x": (8, H, W)}            # stored as [H][W/2] pixel pairs of 8 channels (4 per pixel)
         arr = (capi.FvpBbOp * len(self._convs))()
         names = ["x"]
         w_off, e_off = 0, 64                   # eblob[0:64] stays zero: the DMA's zero page
@@ -151,11 +151,13 @@ class PoseResNet(ParamTree):
                 names.append(o["dst"])
                 dst = len(names) - 1
             res = names.index(o["res"]) if o.get("res") else -1
-            flags = (capi.EPI_RELU if o.get("relu") else 0) | (capi.BB_OUT_HEAT if o.get("heat") else 0)
+            flags = (capi.EPI_RELU if o.get("relu") else 0) | (capi.BB_OUT_HEAT if o.get("heat") else 0) | \
+                (capi.BB_STEM if o.get("stem") else 0)
             arr[i] = capi.FvpBbOp(o["kind"], names.index(o["src"]), dst, res, o["cin"], cin_buf, o["cout"], coutp,
                                   o["cout"], k, k, s_, p_, h, w, oh, ow, flags, w_off, e_off)
             if o["kind"] != capi.BB_MAXPOOL:
-                w_off += (4 if o["kind"] == capi.BB_DECONV else 1) * coutp * (4 if o["kind"] == capi.BB_DECONV else k * k) * cin_buf
+                taps = 28 if o.get("stem") else (4 if o["kind"] == capi.BB_DECONV else k * k)
+                w_off += (4 if o["kind"] == capi.BB_DECONV else 1) * coutp * taps * cin_buf
                 e_off += 2 * coutp
         plan = dict(ops=arr, names=names, shapes=shapes, w_elems=w_off, e_elems=e_off, out_hw=(oh, ow))
         self._plans[(H, W)] = plan
@@ -203,7 +205,7 @@ class PoseResNet(ParamTree):
                     last_use[b] = i
         pool, bufs = {}, [None] * len(plan["names"])
         c, h, w = plan["shapes"]["x"]
-        bufs[0] = torch.empty((N, h, w, c), dtype=torch.bfloat16, device=dev)
+        bufs[0] = torch.empty((N, h, w // 2, c), dtype=torch.bfloat16, device=dev)
         capi.check(self.lib, self.lib.fvp_bb_input(C.c_void_p(x.contiguous().data_ptr()), C.c_void_p(bufs[0].data_ptr()), N, 3,
                                                    H, W, s), "fvp_bb_input")
         for i, op in enumerate(plan["ops"]):                     # allocation plan only (launch order = op order)

@@ -241,7 +241,8 @@ int fvp_rasterise_heatmaps(const double* joints, const int32_t* num_people, int 
  * FVP_BB_OUT_HEAT (final_layer) writes fp32 heatmaps: channels-last [N][H*W][heat_jp] (what the projection
  * kernels read) and / or NCHW [N][J][H][W] (the reference's layout). */
 enum { FVP_BB_CONV = 0, FVP_BB_MAXPOOL = 1, FVP_BB_DECONV = 2 };
-enum { FVP_BB_OUT_HEAT = 8 };   /* with FVP_EPI_RELU = 1 in `flags` */
+enum { FVP_BB_OUT_HEAT = 8,      /* with FVP_EPI_RELU = 1 in `flags` */
+       FVP_BB_STEM = 16 };       /* the 7x7 / stride-2 stem on a <= 4-channel image: pixel-pair form (fvp_backbone.hip) */
 typedef struct FvpBbOp {
   int32_t kind;
   int32_t src, dst, res;      /* activation buffer ids (dst = -1 for the heatmap op, res = -1 if unused) */
@@ -253,7 +254,7 @@ typedef struct FvpBbOp {
   int32_t w_off;              /* bf16 element offset of the packed weights in wblob                     */
   int32_t e_off;              /* float offset of scale | shift (2 * coutp) in eblob                      */
 } FvpBbOp;
-/* images [N][C<=8][H][W] fp32 -> NHWC bf16 with 8 channels */
+/* images [N][C<=4][H][W] fp32 (W even) -> NHWC bf16 with 4 channels per pixel = [N][H][W/2][8] pixel pairs */
 int fvp_bb_input(const float* images, uint16_t* nhwc8, int N, int C, int H, int W, fvp_stream_t s);
 /* state_dict tensors of one conv (+ its BatchNorm, may be NULL) -> packed bf16 weights [cls][coutp][taps*cinp]
  * and fp32 scale | shift (resnet.py conv / bn / deconv / final_layer modules) */
