@@ -185,6 +185,10 @@ class PoseResNet(ParamTree):
             rc = self.lib.fvp_bb_pack(ptr(w), ptr(b), *[ptr(t) for t in bn], BN_EPS, C.byref(plan["ops"][i]), ptr(wblob),
                                       ptr(eblob), s)
             capi.check(self.lib, rc, "fvp_bb_pack " + o["key"])
+        if dev.type == "cuda":
+            # one-time: the packed blobs may be consumed from other streams right away (one backbone shared by
+            # the replicas of a PipelinedForward), so packing completes before anyone can see _dirty == False
+            torch.cuda.current_stream(dev).synchronize()
         self.__dict__["_wblob"], self.__dict__["_eblob"] = wblob, eblob
         self.__dict__["_dirty"] = False
 
