@@ -371,6 +371,12 @@ def test_end_to_end_images_to_joints_config5_shape():
         f2, p2, c2, _, _ = model(meta=meta, input_heatmaps=heat.clone(), cameras=cams, resize_transform=rt)
     assert torch.equal(fused, f2) and torch.equal(centers, c2)
     assert torch.isfinite(fused).all()
+    # the same through three batches in flight sharing the one backbone instance
+    pipe = FV.PipelinedForward(model, depth=3)
+    outs = [pipe.submit(backbone=bb, views=views, meta=meta, cameras=cams, resize_transform=rt) for _ in range(4)]
+    pipe.synchronize()
+    for (pf, _, pc, ph, _), _ in outs:
+        assert torch.equal(pf, fused) and torch.equal(pc, centers) and torch.equal(ph, heat)
 
 
 @pytest.mark.gpu
