@@ -166,6 +166,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # transparency: the strictly serial rate (one batch at a time on the current stream), 5 steps
+        serial_fps = None
+        if nstreams > 1 and graphed is None:
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(5):
+                step(0, pipelined=False)
+            torch.cuda.synchronize()
+            serial_fps = 5 * B * world / (time.perf_counter() - ts)
         # per-class kernel timers (HIP events on the launch stream) in their own untimed steps:
         # the event pairs cost ~2 % and would serialise nothing but still perturb the timed region
         if not args.no_prof and graphed is None:
@@ -260,6 +269,7 @@ def main():
                        "parallelism": f"frame-sharded dp{world}, all_gather of results",
                        "launch": "hipGraph replay" if args.graph else "eager (ctypes launches on the current stream)",
                        "batches_in_flight": nstreams,
+                       "frames_per_s_one_batch_at_a_time": serial_fps,
                        "input": ("5 x [3,512,960] images per frame -> bf16 Pose-ResNet-50 -> voxel path" if args.backbone
                                  else "heatmaps resident in HBM")},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
