@@ -53,7 +53,7 @@ def cpu_baseline(cfg_name, frames, seed):
     golden vectors) on the host cores of this box, same workload, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fvp_oracle as O
-    import faster_voxelpose_amd.synthetic as S
+    import fvp_synthetic as S
     cfg = S.make_cfg(cfg_name, device="cpu", min_score=-1.0)
     cams, seq = S.load_cameras(cfg_name)
     rt = S.resize_transform(cfg)
@@ -103,7 +103,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    import faster_voxelpose_amd.synthetic as S
+    import fvp_synthetic as S
     from faster_voxelpose_amd import _capi as capi
     from faster_voxelpose_amd.models import faster_voxelpose as FV
 

@@ -107,7 +107,8 @@ def load():
         _lib = bind(C.CDLL(LIB_PATH))
         if _lib.fvp_version() != ABI_VERSION:
             raise FvpError("libfvp_hip.so ABI version mismatch (rebuild with faster-voxelpose_amd/csrc/build.sh)")
-        if _lib.fvp_sizeof(0) != C.sizeof(FvpGeom) or _lib.fvp_sizeof(1) != C.sizeof(FvpConvOp):
+        if _lib.fvp_sizeof(0) != C.sizeof(FvpGeom) or _lib.fvp_sizeof(1) != C.sizeof(FvpConvOp) \
+                or _lib.fvp_sizeof(2) != C.sizeof(FvpBbOp):
             raise FvpError("libfvp_hip.so struct layout differs from the ctypes mirrors in _capi.py")
     return _lib
 

@@ -599,13 +599,9 @@ static int bb_launch(const BbConvArgs& a, dim3 grid, hipStream_t s) {
   constexpr size_t lds_ab = (FVP_BB_NBUF * 128 * 72 + FVP_BB_NBUF * BN * 72) * sizeof(uint16_t) + 128;
   constexpr size_t lds_ep = 4 * 64 * 36 * sizeof(float);               // epilogue tiles reuse the same memory
   constexpr size_t lds = lds_ab > lds_ep ? lds_ab : lds_ep;
-  static bool attr = false;
+  static LdsOptIn optin;
   auto k = &k_bb_conv<BN>;
-  if (!attr && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return int(e);
-    attr = true;
-  }
+  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds)) return e;
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
   return launch_status();
 }
@@ -619,12 +615,8 @@ static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const 
   if (!no_big && op.coutp % 256 == 0 && long(ceil_div(M, 256)) * (op.coutp / 256) * a.ncls >= big_min && a.out && !a.out_cl &&
       !a.out_nchw && (a.Cbuf & 7) == 0 && size_t(op.coutp) * a.K < (1u << 30)) {
     constexpr size_t lds = 2 * (256 + 256) * 72 * sizeof(uint16_t) + 128;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bb_conv_big), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      if (e != hipSuccess) return int(e);
-      attr = true;
-    }
+    static LdsOptIn optin;
+    if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(&k_bb_conv_big), lds)) return e;
     hipLaunchKernelGGL(k_bb_conv_big, dim3(ceil_div(M, 256), op.coutp / 256, a.ncls), dim3(512), lds, s, a, zeros);
     return launch_status();
   }

@@ -69,6 +69,23 @@ inline int launch_status() {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is per (function, device): one
+// flag bit per device ordinal, so a second GPU used by the same process gets its own opt-in.
+struct LdsOptIn {
+  unsigned long long done = 0;   // bit d: set on device d (benign race: setting twice is harmless)
+};
+inline int lds_opt_in(LdsOptIn& st, const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (unsigned(dev) & 63u);
+  if (__atomic_load_n(&st.done, __ATOMIC_RELAXED) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+  if (e != hipSuccess) return static_cast<int>(e);
+  __atomic_fetch_or(&st.done, bit, __ATOMIC_RELAXED);
+  return 0;
+}
+
 }  // namespace fvp
 
 #define FVP_REQUIRE(cond)            \

@@ -837,13 +837,9 @@ static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int
 
 template <int WC, int WT, int CC, bool RES>
 static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr = false;
+  static LdsOptIn optin;
   auto k = &k_conv_wino<WC, WT, CC, RES>;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return int(e);
-    attr = true;
-  }
+  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), 160 * 1024)) return e;
   hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);
   return launch_status();
 }

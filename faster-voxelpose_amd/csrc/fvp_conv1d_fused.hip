@@ -302,9 +302,8 @@ extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const
   a.out = out;
   const size_t lds = size_t(total + kNB * kWFloats) * sizeof(float);
   FVP_LIMIT(lds <= 160 * 1024);
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1d_fused),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
-    return FVP_ELIMIT;
+  static LdsOptIn optin;
+  if (lds_opt_in(optin, reinterpret_cast<const void*>(&k_conv1d_fused), lds > 64 * 1024 ? 160 * 1024 : 0)) return FVP_ELIMIT;
   ProfScope ps(FVP_K_CONV, as_stream(s), flops, nops, prof_level() >= 1);
   hipLaunchKernelGGL(k_conv1d_fused, dim3(planes), dim3(256), lds, as_stream(s), a);
   return launch_status();

@@ -246,15 +246,9 @@ extern "C" int fvp_softargmax_weightnet(const float* feat, const float* center_g
   if (nP == 0) return 0;
   const size_t lds = (size_t((C * C + 1) & ~1)) * 4 + 12 * 8 + (5 * kMaxF + Hd) * 4;
   FVP_LIMIT(lds <= 160 * 1024);
-  if (lds > 64 * 1024) {                               // jln128: the 64 KB map needs the large-LDS opt-in
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softargmax_weightnet),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return int(e);
-      attr = true;
-    }
-  }
+  static LdsOptIn optin;                               // jln128: the 64 KB map needs the large-LDS opt-in
+  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(&k_softargmax_weightnet), lds > 64 * 1024 ? 160 * 1024 : 0))
+    return e;
   // algorithmic FLOPs of WeightNet's conv (2*9*F per pixel) + MLP, for the profile hook
   ProfScope ps(FVP_K_SOFTARGMAX, as_stream(s), double(nP) * 3 * J * (2.0 * 9 * F * C * C + 2.0 * F * Hd + 2.0 * Hd));
   hipLaunchKernelGGL(k_softargmax_weightnet, dim3(J, 3, nP), dim3(256), lds, as_stream(s), feat, center_grid, wn,

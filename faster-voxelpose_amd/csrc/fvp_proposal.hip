@@ -128,10 +128,8 @@ extern "C" int fvp_nms_topk(const float* hm2d, int B, int X, int Y, int N, float
   FVP_REQUIRE(hm2d && vals && idx && flat && B >= 0 && X > 0 && Y > 0 && N > 0);
   const size_t lds = size_t(X) * Y * 4 + 32;
   FVP_LIMIT(lds <= 160 * 1024 && N <= X * Y);
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nms_topk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          int(lds)) != hipSuccess)
-    return FVP_ELIMIT;
+  static LdsOptIn optin;
+  if (lds_opt_in(optin, reinterpret_cast<const void*>(&k_nms_topk), lds > 64 * 1024 ? 160 * 1024 : 0)) return FVP_ELIMIT;
   if (B == 0) return 0;
   ProfScope ps(FVP_K_OTHER, as_stream(s));
   hipLaunchKernelGGL(k_nms_topk, dim3(B), dim3(256), lds, as_stream(s), hm2d, X, Y, N, vals,

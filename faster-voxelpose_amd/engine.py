@@ -64,7 +64,8 @@ class HotPath:
         ind_bias = -ind_s / 2.0 / whole_s * (fine - 1) - ind_scale * (whole_c - whole_s / 2.0)
         self.fine = [int(v) for v in fine]
         self.ind_consts = torch.cat([ind_scale, ind_bias, whole_s, ind_s]).float().to(dev).contiguous()
-        self.fine_cube = torch.tensor(self.fine + [int(v) for v in cube], dtype=torch.int32, device=dev)
+        # fine[3], cube[3]: HOST array, passed to fvp_person_boxes by value (it becomes kernel arguments)
+        self.fine_cube = (C.c_int32 * 6)(*(self.fine + [int(v) for v in cube]))
         self.fine_dev = torch.tensor(self.fine, dtype=torch.int32, device=dev)
         self.fine_axes = axes(cs.SPACE_SIZE, cs.SPACE_CENTER, self.fine)
         # center_grid [3, C*C, 2] (project_individual.py:37-40): xy at z0, xz at y0, yz at x0
@@ -313,7 +314,7 @@ class HotPath:
         n = centers2d.shape[0]
         boxes = self.scratch("boxes", (n, 9), torch.int32)
         offset = self.scratch("offset", (n, 3))
-        self._call("fvp_person_boxes", _ptr(centers2d), n, _ptr(self.ind_consts), _ptr(self.fine_cube), _ptr(boxes),
+        self._call("fvp_person_boxes", _ptr(centers2d), n, _ptr(self.ind_consts), self.fine_cube, _ptr(boxes),
                    _ptr(offset), self.stream())
         return boxes, offset
 

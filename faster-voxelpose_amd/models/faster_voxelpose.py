@@ -51,6 +51,9 @@ class FasterVoxelPoseNet(nn.Module):
         mask = proposal_centers[:, :, 3] >= 0
         fused_poses, plane_poses = self.joint_net.forward5(meta, input_heatmaps, proposal_centers, mask, cameras,
                                                            resize_transform, _reuse_staging=True)
+        # the channels-last staging copy is valid for this call only: a later tensor may reuse the
+        # same address / version / shape once the caching allocator recycles the block
+        self.engine.invalidate_staging()
         return fused_poses, plane_poses, proposal_centers, input_heatmaps, None
 
 
@@ -111,11 +114,26 @@ class PipelinedForward:
         self._i += 1
         st = self.streams[k]
         st.wait_stream(torch.cuda.current_stream())      # inputs produced on the caller's stream
+        # the inputs were allocated on the caller's stream but are read on `st`: tell the caching
+        # allocator, or a caller that drops them right after submit() could see the block handed
+        # out again (and overwritten on its own stream) while this batch is still queued on `st`
+        for v in forward_kwargs.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(st)
         with torch.cuda.stream(st), torch.no_grad():
             out = self.models[k](**forward_kwargs)
             ev = torch.cuda.Event()
             ev.record(st)
         return out, ev
+
+    @staticmethod
+    def consume(outputs, stream=None):
+        """Declare that ``outputs`` (allocated on a pipeline stream) are about to be read on
+        ``stream`` (default: the current one) so their memory is not recycled under the reader."""
+        stream = stream or torch.cuda.current_stream()
+        for t in outputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
 
     def synchronize(self):
         for st in self.streams:

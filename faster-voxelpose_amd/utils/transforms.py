@@ -13,59 +13,62 @@ import torch
 
 
 def get_scale(image_size, resized_size):
-    """Letter-box scale in units of 200 px (reference transforms.py:81-93)."""
-    w, h = image_size
-    w_resized, h_resized = resized_size
-    if w / w_resized < h / h_resized:
-        w_pad, h_pad = h / h_resized * w_resized, h
+    """Size of the letter-boxed source window in units of 200 px (interface of the reference's
+    transforms.py:81): the original image padded to the aspect ratio of the resized one."""
+    ow, oh = float(image_size[0]), float(image_size[1])
+    rw, rh = float(resized_size[0]), float(resized_size[1])
+    # the axis with the larger original/resized ratio keeps its length, the other is padded
+    if ow / rw < oh / rh:
+        padded = (oh / rh * rw, oh)
     else:
-        w_pad, h_pad = w, w / w_resized * h_resized
-    return np.array([w_pad / 200.0, h_pad / 200.0], dtype=np.float32)
+        padded = (ow, ow / rw * rh)
+    return (np.array(padded, dtype=np.float64) / 200.0).astype(np.float32)
 
 
-def _third_point(a, b):
-    d = a - b
-    return b + np.array([-d[1], d[0]], dtype=np.float32)
+def _triangle(origin, arm):
+    """float32 triangle (origin, origin + arm, perpendicular completion of that edge at its
+    far end) - the three control points the reference hands to OpenCV (transforms.py:36-44);
+    the completion is done in float32 as there, which is why the result is a similarity only
+    up to float32 rounding of the third vertex."""
+    tri = np.empty((3, 2), dtype=np.float32)
+    tri[0] = origin
+    tri[1] = np.asarray(origin, dtype=np.float64) + arm
+    edge = tri[0] - tri[1]
+    tri[2] = tri[1] + np.array([-edge[1], edge[0]], dtype=np.float32)
+    return tri
 
 
-def _solve_affine(src, dst):
-    """2x3 affine A with A @ [x, y, 1] = dst for three point pairs (float64)."""
+def _affine_from_triangles(src, dst):
+    """2x3 affine A with A @ [x, y, 1] = dst for the three vertex pairs, solved in float64."""
     m = np.concatenate([src.astype(np.float64), np.ones((3, 1))], axis=1)
-    sol = np.linalg.solve(m, dst.astype(np.float64))          # [3, 2]
-    return sol.T.copy()                                        # [2, 3]
+    return np.linalg.solve(m, dst.astype(np.float64)).T.copy()
 
 
 def get_affine_transform(center, scale, rot, output_size,
                          shift=np.array([0, 0], dtype=np.float32), inv=0):
-    """Centre/scale/rotation -> 2x3 affine (reference transforms.py:15-49)."""
-    if isinstance(scale, torch.Tensor):
-        scale = np.array(scale.cpu())
-    if isinstance(center, torch.Tensor):
-        center = np.array(center.cpu())
-    if not isinstance(scale, (np.ndarray, list)):
-        scale = np.array([scale, scale])
-    scale_tmp = np.asarray(scale) * 200.0
-    src_w, src_h = scale_tmp[0], scale_tmp[1]
-    dst_w, dst_h = output_size[0], output_size[1]
-    rot_rad = np.pi * rot / 180
-    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
-    if src_w >= src_h:
-        p = [0, src_w * -0.5]
-        dst_dir = np.array([0, dst_w * -0.5], np.float32)
-    else:
-        p = [src_h * -0.5, 0]
-        dst_dir = np.array([dst_h * -0.5, 0], np.float32)
-    src_dir = [p[0] * cs - p[1] * sn, p[0] * sn + p[1] * cs]
+    """Centre / scale (units of 200 px) / rotation (degrees) -> 2x3 affine into an
+    ``output_size`` window (interface of the reference's transforms.py:15).
 
-    src = np.zeros((3, 2), dtype=np.float32)
-    dst = np.zeros((3, 2), dtype=np.float32)
-    src[0, :] = center + scale_tmp * shift
-    src[1, :] = center + src_dir + scale_tmp * shift
-    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
-    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
-    src[2, :] = _third_point(src[0, :], src[1, :])
-    dst[2, :] = _third_point(dst[0, :], dst[1, :])
-    return _solve_affine(dst, src) if inv else _solve_affine(src, dst)
+    The longer source side is mapped onto the same side of the output: a half-side "arm"
+    (pointing up for a wide source, left for a tall one) is attached to the source anchor
+    ``center + shift * size`` - rotated by ``rot`` - and to the output centre - unrotated; the two
+    triangles spanned by anchor, arm and the arm's perpendicular define the affine."""
+    size = np.asarray(scale.cpu() if isinstance(scale, torch.Tensor) else scale)
+    if size.ndim == 0:
+        size = np.array([size, size])
+    size = size * 200.0
+    anchor = np.asarray(center.cpu() if isinstance(center, torch.Tensor) else center) + size * shift
+    out_w, out_h = output_size[0], output_size[1]
+    wide = size[0] >= size[1]
+    half_src = float(-0.5 * (size[0] if wide else size[1]))
+    half_dst = float(np.float32(-0.5 * (out_w if wide else out_h)))
+    axis = 1j if wide else 1.0                              # unit vector of the arm: +y or +x
+    turn = complex(np.cos(np.pi * rot / 180), np.sin(np.pi * rot / 180))
+    arm_src = half_src * axis * turn
+    arm_dst = half_dst * axis
+    src = _triangle(anchor, np.array([arm_src.real, arm_src.imag]))
+    dst = _triangle([out_w * 0.5, out_h * 0.5], np.array([arm_dst.real, arm_dst.imag]))
+    return _affine_from_triangles(dst, src) if inv else _affine_from_triangles(src, dst)
 
 
 def get_resize_transform(ori_image_size, image_size):

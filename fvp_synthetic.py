@@ -1,5 +1,8 @@
 """Synthetic configs, cameras, heatmaps and weights for tests / smoke / bench.
 
+Measurement / test infrastructure: lives beside ``bench.py`` at the repo root, outside the product
+package (which never imports it).
+
 No dataset or checkpoint can be fetched offline, so every measurement and parity case in
 this repo runs on the recipes below.  Everything is derived from
 numpy ``PCG64`` streams keyed by (seed, name), so the build container (which generates
@@ -20,7 +23,7 @@ from types import SimpleNamespace as NS
 import numpy as np
 import torch
 
-_FIXTURES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+_FIXTURES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
 
 SHAPES = {
     "panoptic": dict(V=5, J=15, hm=[240, 128], img=[960, 512], ori=[1920, 1080],
@@ -82,7 +85,7 @@ def load_cameras(name):
 
 
 def resize_transform(cfg):
-    from .utils.transforms import get_resize_transform
+    from faster_voxelpose_amd.utils.transforms import get_resize_transform
     return torch.as_tensor(get_resize_transform(cfg.DATASET.ORI_IMAGE_SIZE, cfg.DATASET.IMAGE_SIZE),
                            dtype=torch.float32)
 
@@ -118,7 +121,7 @@ def heatmaps_blobs(cfg, cameras, seq, batch, people=4, seed=3, sigma=3.0):
     ``people`` synthetic skeletons per frame, max-combined per joint, clipped to [0,1].
     Mirrors what the reference's data layer feeds on the precomputed-heatmap path
     (lib/dataset/JointsDataset.py:271-338) without sharing its code."""
-    from .utils.transforms import get_resize_transform
+    from faster_voxelpose_amd.utils.transforms import get_resize_transform
     w, h = cfg.DATASET.HEATMAP_SIZE
     V, J = cfg.DATASET.CAMERA_NUM, cfg.DATASET.NUM_JOINTS
     rt = get_resize_transform(cfg.DATASET.ORI_IMAGE_SIZE, cfg.DATASET.IMAGE_SIZE)

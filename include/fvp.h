@@ -88,8 +88,9 @@ int fvp_zmax(const float* cubes, float* zmax, long n, int Z, fvp_stream_t s);
  * (int32), offset (mm), margin from the bbox, start/end clipped to the fine grid.  boxes =
  * [n][9] int32 = tl[3], start[3], end[3]; offset = [n][3].  Bit-exact with
  * project_individual.ProjectLayer.forward :110-121.  consts = scale[3], bias[3], whole[3],
- * ind[3] (12 floats, host-side values of project_individual.py:22-30 uploaded once);
- * fine[3], cube[3] by value. */
+ * ind[3] (12 floats, device memory: host-side values of project_individual.py:22-30 uploaded once);
+ * fine_cube = fine[3], cube[3]: six int32 in HOST memory, read at call time and passed to the
+ * kernel by value (the only host-memory pointer argument of this ABI besides FvpGeom / op lists). */
 int fvp_person_boxes(const float* centers, int n, const float* consts, const int32_t* fine_cube,
                      int32_t* boxes, float* offset, fvp_stream_t s);
 

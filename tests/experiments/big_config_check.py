@@ -10,7 +10,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import torch  # noqa: E402
 
 import fvp_oracle as O  # noqa: E402
-import faster_voxelpose_amd.synthetic as S  # noqa: E402
+import fvp_synthetic as S  # noqa: E402
 from faster_voxelpose_amd.models import faster_voxelpose as FV  # noqa: E402
 
 vox, cube = [128, 128, 32], [128, 128, 128]

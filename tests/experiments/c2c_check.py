@@ -1,6 +1,6 @@
 import sys; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
 import numpy as np, torch
-import faster_voxelpose_amd.synthetic as S
+import fvp_synthetic as S
 from faster_voxelpose_amd.models import faster_voxelpose as FV
 import fvp_oracle as O
 cfg = S.make_cfg("panoptic", device="cuda:0")

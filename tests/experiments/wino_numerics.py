@@ -8,7 +8,7 @@ sys.path[:0] = [R, os.path.join(R, "oracle"), os.path.join(R, "tests"), os.path.
 import fvp_oracle as O
 from cases import CASES, make_inputs
 from common import load_golden, joint_errors
-import faster_voxelpose_amd.synthetic as S
+import fvp_synthetic as S
 
 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32)
 Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)

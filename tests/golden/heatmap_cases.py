@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import faster_voxelpose_amd.synthetic as S  # noqa: E402
+import fvp_synthetic as S  # noqa: E402
 
 HEATMAP_CASES = {
     # name -> (shape set, people per view, seed, sigma)

@@ -4,7 +4,7 @@
 
 Imports ``/root/reference/lib`` (via ``_refimport``), builds ``FasterVoxelPoseNet`` for each
 case below with the seeded synthetic weights / heatmaps of
-``faster_voxelpose_amd.synthetic``, runs its eval forward on CPU and stores *data only*:
+``fvp_synthetic``, runs its eval forward on CPU and stores *data only*:
 the recipe (seeds, config name), the reference's outputs and compact digests of its big
 intermediates.  Inputs are not stored; they are regenerated from the recipe.
 
@@ -35,7 +35,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import _refimport as R  # noqa: E402
-import faster_voxelpose_amd.synthetic as S  # noqa: E402
+import fvp_synthetic as S  # noqa: E402
 import fvp_oracle as O  # noqa: E402
 
 from cases import CASES, make_inputs  # noqa: E402

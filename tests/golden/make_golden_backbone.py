@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, HERE]
 import _refimport as R  # noqa: E402
-import faster_voxelpose_amd.synthetic as S  # noqa: E402
+import fvp_synthetic as S  # noqa: E402
 from faster_voxelpose_amd.core import config as CFG  # noqa: E402
 
 SHAPE, WSEED, XSEED = (2, 3, 96, 128), 3, 5

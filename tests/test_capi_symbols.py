@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_product_refuses_cpu_device():
     """No CPU fallback: building the model for a non-GPU device fails loudly."""
-    import faster_voxelpose_amd.synthetic as S
+    import fvp_synthetic as S
     from faster_voxelpose_amd.models import faster_voxelpose as FV
     with pytest.raises(capi.FvpError):
         FV.get(S.make_cfg("tiny", device="cpu"))
@@ -44,7 +44,7 @@ def test_product_refuses_cpu_device():
 def test_state_dict_keys_match_reference_list():
     """485 entries with the reference's prefixes (checkpoint row); the full
     ordered key list was compared with the imported reference in the build container."""
-    import faster_voxelpose_amd.synthetic as S
+    import fvp_synthetic as S
     from faster_voxelpose_amd.models import faster_voxelpose as FV
     lib = object()          # never called: construction only
     m = FV.FasterVoxelPoseNet(S.make_cfg("panoptic", device="cpu"), _lib=lib)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-import faster_voxelpose_amd.synthetic as S
+import fvp_synthetic as S
 from faster_voxelpose_amd.core import config as CFG
 from faster_voxelpose_amd.utils import checkpoint as CK
 
@@ -76,8 +76,11 @@ def test_checkpoint_flavours(tmp_path):
     best = tmp_path / "model_best.pth.tar"                      # bare state_dict (utils.py:92-98)
     torch.save(sd, best)
     full = tmp_path / "checkpoint.pth.tar"                      # full checkpoint with a backbone and DataParallel prefix
+    # as run/train.py writes it: 'precision' is an np.float64 (np.mean of the APs), plus an optimizer state
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=1e-4)
     torch.save({"epoch": 7, "state_dict": {**{"module." + k: v for k, v in sd.items()},
-                                            "module.backbone.conv1.weight": torch.zeros(4)}}, full)
+                                            "module.backbone.conv1.weight": torch.zeros(4)},
+                "precision": np.float64(0.875), "aps": np.array([0.5, 0.75]), "optimizer": opt.state_dict()}, full)
     for path in (best, full):
         m = FV.FasterVoxelPoseNet(cfg, _lib=object())
         rep = CK.load_model_file(m, str(path))
@@ -92,3 +95,22 @@ def test_checkpoint_flavours(tmp_path):
     with pytest.raises(ValueError, match="neither a state_dict"):
         torch.save([1, 2, 3], best)
         CK.read_state_dict(str(best))
+
+
+def test_affine_transform_matches_reference_golden():
+    """get_affine_transform / get_scale against outputs of the reference's own functions
+    (tests/golden/make_golden_transforms.py; lib/utils/transforms.py:15,81)."""
+    from faster_voxelpose_amd.utils import transforms as T
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms.npz"))
+    for i in range(len(g["rot"])):
+        a = T.get_affine_transform(g["center"][i], g["scale"][i], g["rot"][i], g["out"][i], shift=g["shift"][i],
+                                   inv=int(g["inv"][i]))
+        assert np.array_equal(a, g["affine"][i]), i
+    for (a, b, c, d), want in zip(g["sizes"], g["scales"]):
+        got = T.get_scale((int(a), int(b)), (int(c), int(d)))
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+    # scalar scale and torch inputs are accepted like the reference does
+    t1 = T.get_affine_transform(torch.tensor([5.0, 6.0]), torch.tensor([2.0, 3.0]), 30, (64, 48))
+    t2 = T.get_affine_transform(np.array([5.0, 6.0]), np.array([2.0, 3.0], np.float32), 30, (64, 48))
+    assert np.array_equal(t1, t2)
+    assert T.get_affine_transform(np.array([5.0, 6.0]), 2.0, 0, (64, 48)).shape == (2, 3)

@@ -14,7 +14,7 @@ import torch
 import fvp_oracle as O
 from cases import make_inputs
 from common import check_outputs, load_golden
-import faster_voxelpose_amd.synthetic as S
+import fvp_synthetic as S
 from faster_voxelpose_amd.models import faster_voxelpose as FV
 
 

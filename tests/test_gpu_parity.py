@@ -11,7 +11,7 @@ import torch
 import fvp_oracle as O
 from cases import CASES, make_inputs
 from common import check_outputs, load_golden
-import faster_voxelpose_amd.synthetic as S
+import fvp_synthetic as S
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

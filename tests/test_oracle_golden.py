@@ -7,7 +7,7 @@ import torch
 import fvp_oracle as O
 from cases import CASES, make_inputs
 from common import load_golden
-import faster_voxelpose_amd.synthetic as S
+import fvp_synthetic as S
 
 
 def state_dict_for(cfg, wseed):

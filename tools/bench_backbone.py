@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-import faster_voxelpose_amd.synthetic as S  # noqa: E402
+import fvp_synthetic as S  # noqa: E402
 from faster_voxelpose_amd.core import config as CFG  # noqa: E402
 from faster_voxelpose_amd.models import resnet as RN  # noqa: E402
 

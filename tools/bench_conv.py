@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-import faster_voxelpose_amd.synthetic as S  # noqa: E402
+import fvp_synthetic as S  # noqa: E402
 from faster_voxelpose_amd import _capi as capi  # noqa: E402
 from faster_voxelpose_amd.engine import _ptr  # noqa: E402
 from faster_voxelpose_amd.models import faster_voxelpose as FV  # noqa: E402
