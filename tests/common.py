@@ -7,13 +7,27 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# north_star bar: 3-D joints within 1e-3 mm of the reference.  The reference's own fp32
-# arithmetic is only reproducible to its rounding-noise floor (fp32 vs the same nets in fp64,
-# stored per fixture as margins[5]: 3e-3 .. 5e-2 mm, SURVEY.md section 7 hard part 1), and a
-# different summation order inside the convs lands anywhere within that floor.  So: pass at
-# <= 1e-3 mm, or when both |build - ref32| and |build - ref64| stay within FLOOR_FACTOR x floor.
+# north_star bar: 3-D joints within 1e-3 mm of the reference.
+#  * conditioned fixtures (flavour "c" in cases.py: trained-like single-mode joint maps; the
+#    reference's own fp32-vs-fp64 floor is <= ~4e-4 mm): |build - reference| <= 1e-3 mm, no escape.
+#  * stress fixtures (random weights -> multi-modal joint maps with near-ties, uniform-noise
+#    heatmaps): the reference's fp32 result itself is only reproducible to its rounding-noise floor
+#    (fp32 vs the same nets in fp64, stored per fixture as margins[5]: 3e-3 .. 9e-2 mm), and any other
+#    summation order inside the convs lands anywhere within that floor.  There: pass at <= 1e-3 mm, or
+#    when |build - ref32| <= FLOOR_FACTOR x floor AND the distance to the float64 evaluation
+#    |build - ref64| is <= 1e-3 mm -- except for the cases listed in FP64_EXCEPTIONS.
 BAR_MM = 1e-3
 FLOOR_FACTOR = 3.0
+# |build - ref64| bound (mm) where it is not <= 1e-3: the three uniform-noise heatmap fixtures.  Their
+# joint maps are almost flat (softmax mass spread over the whole 2 m cube, mean absolute deviation
+# ~500 mm), so the build's own fp32 conv rounding (|d feat| ~ 1e-7, times beta = 100, times 500 mm)
+# moves the expectation by a few 1e-3 mm, exactly like the reference's (floors 5e-3 .. 5e-2 mm there).
+FP64_EXCEPTIONS = {"tiny_u_b3_thr": 3e-3, "campus_u_b2_all": 4e-3, "panoptic_u_b1_all": 6e-3}
+
+
+def is_conditioned(case):
+    from cases import CASES
+    return CASES[case][1] == "c"
 
 
 def load_golden(case):
@@ -83,7 +97,11 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
                       mean_mm_vs_ref=float(e32.mean()) if e32.size else 0.0,
                       max_mm_vs_fp64=float(e64.max()) if e64.size else 0.0, ref_floor_mm=floor)
     if e32.size:
-        ok = e32.max() <= BAR_MM or (e32.max() <= FLOOR_FACTOR * floor and e64.max() <= FLOOR_FACTOR * floor)
+        if is_conditioned(case):
+            ok = e32.max() <= BAR_MM                       # the north-star bar itself
+        else:
+            ok = e32.max() <= BAR_MM or (e32.max() <= FLOOR_FACTOR * floor and
+                                         e64.max() <= FP64_EXCEPTIONS.get(case, BAR_MM))
         assert ok, f"{case}: |build-ref32| max {e32.max():.2e} mm, |build-ref64| max {e64.max():.2e} mm, " \
                    f"reference fp32 noise floor {floor:.2e} mm"
     f = fused.detach().cpu().numpy()
@@ -91,5 +109,5 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
     assert np.all(f[..., :3][~v] == 0.0), "invalid proposals must have zero joints"
     np.testing.assert_allclose(f[..., 4], g["fused_poses"][..., 4], rtol=2e-4, atol=1e-6)
     pl = planes.detach().cpu().numpy()
-    tol = max(BAR_MM, FLOOR_FACTOR * floor) * 2
+    tol = BAR_MM if is_conditioned(case) else max(BAR_MM, FLOOR_FACTOR * floor) * 2
     np.testing.assert_allclose(pl, g["plane_poses"], rtol=0, atol=tol)

@@ -23,15 +23,37 @@ CASES = {
     "panoptic128_g_b1_all": ("panoptic128", "g", 1, 4, 10, 7, -1.0),
 }
 
+# Float-parity fixtures (flavour "c": conditioned weights + people heatmaps, SURVEY.md section 7 hard
+# part 1): the reference's own fp32-vs-fp64 noise floor on these is <= ~3e-4 mm, so the north-star bar
+# |build - reference| <= 1e-3 mm is asserted on them WITHOUT a noise-floor escape.  Heatmap seed and
+# MIN_SCORE were picked by tests/golden/find_conditioned.py (every proposal above the threshold is a
+# person with single-mode joint maps, and the threshold sits in a >= 15 % confidence gap).
+CONDITIONED = dict(sigma=2.5, region=1400.0, spacing=1400.0, joint_std=(120.0, 120.0, 250.0))
+CASES.update({
+    "panoptic_c_b2_thr": ("panoptic", "c", 2, [6, 5], 6, 7, 0.387),        # 4 + 4 valid people
+    "shelf_c_b1_thr": ("shelf", "c", 1, 5, 3, 11, 0.435),                  # 3 valid people
+})
+
 
 def make_inputs(case, device="cpu"):
     shape, flavour, B, people, hseed, wseed, ms = CASES[case]
     cfg = S.make_cfg(shape, device=device, min_score=ms)
     cams, seq = S.load_cameras(shape)
     rt = S.resize_transform(cfg)
-    if flavour == "g":
+    if flavour == "c":
+        heat = S.heatmaps_people(cfg, cams, seq, B, people, seed=hseed, **CONDITIONED)
+    elif flavour == "g":
         heat = S.heatmaps_blobs(cfg, cams, seq, B, people=people, seed=hseed)
     else:
         heat = S.heatmaps_uniform(cfg, B, seed=hseed)
     meta = {"seq": [seq] * B}
     return cfg, cams, seq, rt, heat, meta, wseed
+
+
+def make_weights(case, state_dict_like):
+    """Seeded weights of a case for every key of ``state_dict_like`` (a model's state_dict or the
+    oracle's key -> zeros map): the conditioned recipe for flavour "c", the generic one otherwise."""
+    flavour, wseed = CASES[case][1], CASES[case][5]
+    if flavour == "c":
+        return S.fill_state_dict_conditioned(state_dict_like, seed=wseed)
+    return S.fill_state_dict(state_dict_like, seed=wseed)

@@ -38,14 +38,14 @@ import _refimport as R  # noqa: E402
 import fvp_synthetic as S  # noqa: E402
 import fvp_oracle as O  # noqa: E402
 
-from cases import CASES, make_inputs  # noqa: E402
+from cases import CASES, make_inputs, make_weights  # noqa: E402
 
 
 def run_case(ref, case):
     cfg, cams, seq, rt, heat, meta, wseed = make_inputs(case)
     with R.quiet():
         model = ref.faster_voxelpose.get(cfg).eval()
-    sd = S.fill_state_dict(model.state_dict(), seed=wseed)
+    sd = make_weights(case, model.state_dict())
     model.load_state_dict(sd)
     B = heat.shape[0]
     N = cfg.CAPTURE_SPEC.MAX_PEOPLE

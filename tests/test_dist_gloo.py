@@ -1,5 +1,8 @@
 """The N>1 path of bench.py (frame sharding + all_gather of results) on CPU: world_size 2,
-gloo backend.  Checks the sharded result equals the single-process result bit for bit."""
+gloo backend.  Checks that the sharded result equals the single-process result bit for bit, and the
+stream-ordering contract of the gather (the gather of batch t overlaps the
+compute of batch t+1): the collective waits for the batch's completion event only, on its own stream,
+and nothing the compute pipeline waits on ever carries a collective."""
 import os
 import sys
 
@@ -18,33 +21,100 @@ def _fake_hot_path(frames):
     return (frames.view(-1, 1, 1, 1) * w.view(1, 1, 1, 5)).repeat(1, 10, 15, 1)
 
 
+class _LogStream:
+    """Records what is enqueued on / waited for by a stream (stands in for a HIP stream)."""
+
+    def __init__(self, name, log):
+        self.name, self.log = name, log
+
+    def wait_event(self, ev):
+        self.log.append((self.name, "wait_event", ev))
+
+    def wait_stream(self, other):
+        self.log.append((self.name, "wait_stream", other.name))
+
+    def synchronize(self):
+        self.log.append((self.name, "synchronize", None))
+
+
+class _Ctx:
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.stream.log.append((self.stream.name, "enter", None))
+
+    def __exit__(self, *a):
+        self.stream.log.append((self.stream.name, "exit", None))
+
+
+class _MockPipeline:
+    """PipelinedForward.submit's stream semantics: batch i runs on stream i % depth after waiting for
+    the CALLER's stream (where the inputs were produced); returns (result, completion event)."""
+
+    def __init__(self, depth, current, log):
+        self.streams = [_LogStream(f"compute{k}", log) for k in range(depth)]
+        self.current, self.log, self.i = current, log, 0
+
+    def submit(self, frames):
+        st = self.streams[self.i % len(self.streams)]
+        st.wait_stream(self.current)
+        ev = f"done{self.i}"
+        self.log.append((st.name, "record", ev))
+        self.i += 1
+        return _fake_hot_path(frames), ev
+
+
 def _worker(rank, world, port, total, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import bench
-    lo, hi = bench.shard_frames(total, world, rank)
-    local = _fake_hot_path(torch.arange(lo, hi, dtype=torch.float32))
-    out = bench.gather_results(local, world)
+    from faster_voxelpose_amd.core import distributed as D
+    lo, hi = D.shard_frames(total, world, rank)
+    log = []
+    current = _LogStream("current", log)
+    comm = _LogStream("comm", log)
+    pipe = _MockPipeline(3, current, log)
+    gat = D.ResultGatherer(world, stream=comm, stream_ctx=_Ctx)
+    outs = []
+    for step in range(4):                                   # 4 steps, 3 batches in flight
+        local, ev = pipe.submit(torch.arange(lo, hi, dtype=torch.float32) + 100 * step)
+        outs.append(gat.gather(local, ev).clone())
+    gat.synchronize()
     dist.barrier()
     if rank == 0:
-        q.put(out)
+        q.put((outs, log))
     dist.destroy_process_group()
 
 
-def test_sharded_gather_equals_single_process():
-    import bench
+def test_sharded_gather_equals_single_process_and_never_fences_the_pipeline():
+    from faster_voxelpose_amd.core import distributed as D
     total, world = 8, 2
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_worker, args=(r, world, 29611, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get()
+    outs, log = q.get()
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    want = _fake_hot_path(torch.arange(0, total, dtype=torch.float32))
-    assert torch.equal(out, want)
-    assert bench.shard_frames(8, 2, 1) == (4, 8)
-    assert torch.equal(bench.gather_results(want, 1), want)
+    for step, out in enumerate(outs):
+        want = _fake_hot_path(torch.arange(0, total, dtype=torch.float32) + 100 * step)   # rank r's rows at [r*4,(r+1)*4)
+        want = torch.cat([_fake_hot_path(torch.arange(r * 4, r * 4 + 4, dtype=torch.float32) + 100 * step)
+                          for r in range(world)])
+        assert torch.equal(out, want)
+    # ordering contract
+    comm_ops = [e for e in log if e[0] == "comm"]
+    assert [e[2] for e in comm_ops if e[1] == "wait_event"] == ["done0", "done1", "done2", "done3"]
+    assert not any(e[1] == "wait_stream" for e in comm_ops)
+    compute_waits = [e for e in log if e[0].startswith("compute") and e[1] in ("wait_stream", "wait_event")]
+    assert compute_waits and all(e[1] == "wait_stream" and e[2] == "current" for e in compute_waits), \
+        "a compute stream may only wait for the submitting stream"
+    assert not any(e[0] == "current" for e in log), "the submitting stream must carry neither collectives nor waits"
+    # batch t+1 is submitted before gather t is synchronised: the only synchronize is the final one
+    assert [e for e in log if e[1] == "synchronize"] == [("comm", "synchronize", None)]
+    # world == 1: identity, no streams
+    x = _fake_hot_path(torch.arange(0, 8, dtype=torch.float32))
+    assert D.ResultGatherer(1).gather(x) is x
+    assert D.shard_frames(8, 2, 1) == (4, 8)

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import fvp_oracle as O
-from cases import make_inputs
+from cases import make_inputs, make_weights
 from common import check_outputs, load_golden
 import fvp_synthetic as S
 from faster_voxelpose_amd.models import faster_voxelpose as FV
@@ -21,7 +21,7 @@ from faster_voxelpose_amd.models import faster_voxelpose as FV
 def build_model(case, lib):
     cfg, cams, seq, rt, heat, meta, wseed = make_inputs(case)
     model = FV.FasterVoxelPoseNet(cfg, _lib=lib)
-    model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=wseed))
+    model.load_state_dict(make_weights(case, model.state_dict()))
     return model, cfg, cams, seq, rt, heat, meta
 
 
@@ -178,3 +178,19 @@ def test_backbone_emulated_matches_bf16_oracle(emu_lib):
     cl = m.forward_channels_last(x)
     J = cfg.DATASET.NUM_JOINTS
     assert torch.equal(cl[..., :J], y.reshape(1, J, -1).permute(0, 2, 1)) and not cl[..., J:].any()
+
+
+# ---- edge cases shared with the GPU suite (tests/edge_cases.py) ------------------------------------
+import edge_cases as E  # noqa: E402
+
+
+def test_zero_batch_through_every_export(emu_lib):
+    E.zero_batch_through_every_export(emu_lib, "cpu")
+
+
+def test_negative_bbox_gives_an_empty_window(emu_lib):
+    E.negative_bbox_gives_an_empty_window(emu_lib, "cpu")
+
+
+def test_sampling_grids_equal_reference_campus(emu_lib):
+    E.sampling_grids_equal_reference(emu_lib, "cpu", "campus")
