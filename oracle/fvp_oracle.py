@@ -54,11 +54,43 @@ def camera_tensors(cam):
     return R, T, f, c, k, p
 
 
+def _fma32(a, b, c):
+    """Exact fp32 fused multiply-add on any host: the product of two floats is exact in float64;
+    the sum is formed in float64 with ROUND-TO-ODD (TwoSum error term -> if inexact and the double's
+    last mantissa bit is even, step one ulp towards the error), after which the final rounding to
+    float32 is the correctly rounded fma (no double-rounding cases).  Independent of CPU / BLAS."""
+    p = a.double() * b.double()
+    c = c.double()
+    s = p + c
+    t = s - p
+    err = (p - (s - t)) + (c - t)
+    odd = (s.view(torch.int64) & 1) == 1
+    fix = (err != 0) & ~odd
+    toward = torch.where(err > 0, torch.full_like(s, float("inf")), torch.full_like(s, float("-inf")))
+    s = torch.where(fix, torch.nextafter(s, toward), s)
+    return s.float()
+
+
+def _mm3_fma(m, x):
+    """``torch.mm(m, x)`` for a [R,3] matrix as the reference's CPU sgemm evaluates it in the build
+    container: per output a k-ordered chain  fma(m2, x2, fma(m1, x1, m0 * x0))  (found by bit-matching the
+    reference's cached grids).  Spelled out because other CPUs / BLAS builds round the same product
+    differently (observed: the GPU box's EPYC host differs from the golden vectors by a few ulp), and
+    the oracle has to reproduce the GOLDEN arithmetic wherever it runs."""
+    rows = []
+    for i in range(m.shape[0]):
+        acc = m[i, 0] * x[0]
+        acc = _fma32(m[i, 1], x[1], acc)
+        acc = _fma32(m[i, 2], x[2], acc)
+        rows.append(acc)
+    return torch.stack(rows, dim=0)
+
+
 def project_points(pts, cam):
     """World [N,3] -> distorted pixel coordinates [N,2] (lib/utils/cameras.py:30-56).
     No behind-camera test; depth gets +1e-5 (cameras.py:44)."""
     R, T, f, c, k, p = camera_tensors(cam)
-    xc = torch.mm(R, pts.t() - T)                                   # [3,N]
+    xc = _mm3_fma(R, pts.t() - T)                                   # [3,N]  (torch.mm in the reference)
     y0 = xc[0] / (xc[2] + 1e-5)
     y1 = xc[1] / (xc[2] + 1e-5)
     r = y0 * y0 + y1 * y1
@@ -79,7 +111,7 @@ def sample_grid(pts, cam, cfg, resize_transform):
     xy = torch.clamp(xy, -1.0, float(max(ori[0], ori[1])))
     t = torch.as_tensor(np.asarray(resize_transform), dtype=torch.float32)
     homo = torch.cat([xy, torch.ones(xy.shape[0], 1)], dim=1)
-    xy = torch.mm(t, homo.t())[:2].t()
+    xy = _mm3_fma(t, homo.t())[:2].t()                               # torch.mm in the reference (transforms.py:62)
     xy = xy * torch.tensor([w, h], dtype=torch.float32) / torch.tensor(
         cfg.DATASET.IMAGE_SIZE, dtype=torch.float32)
     g = xy / torch.tensor([w - 1, h - 1], dtype=torch.float32) * 2.0 - 1.0
@@ -319,10 +351,19 @@ def person_boxes(spec, centers):
     return tl, offset, start, end
 
 
-def project_individual(spec, cfg, heat, centers, cams, resize_transform):
-    """Per-person cubes [P,J,C,C,C] + offset [P,3] (project_individual.py:96-136).
-    Sampling coordinates are recomputed for the window instead of slicing a cached
-    full-space grid; the arithmetic per point is identical."""
+def fine_sample_grid(spec, cfg, cams, resize_transform):
+    """The per-sequence cache of project_individual.py:82-94: sampling coordinates of the whole fine
+    grid, [V, fx, fy, fz, 2] (164 MB for the Panoptic shape set)."""
+    fine = [int(v) for v in spec.fine]
+    pts = spec.fine_points(torch.zeros(3, dtype=torch.int64), torch.tensor(fine))
+    return build_sample_grids(pts, cams, cfg, resize_transform).view(len(cams), fine[0], fine[1], fine[2], 2)
+
+
+def project_individual(spec, cfg, heat, centers, cams, resize_transform, fine_grid=None):
+    """Per-person cubes [P,J,C,C,C] + offset [P,3] (project_individual.py:96-136).  With
+    ``fine_grid`` (``fine_sample_grid``) the window is sliced out of the cached full-space grid as the
+    reference does (:127-128); without it the coordinates of the window are recomputed - the
+    arithmetic per point is identical."""
     P = centers.shape[0]
     V, J = heat.shape[:2]
     C = [int(c) for c in spec.cube]
@@ -331,8 +372,10 @@ def project_individual(spec, cfg, heat, centers, cams, resize_transform):
     for i in range(P):
         if bool((start[i] >= end[i]).any()):
             continue
-        pts = spec.fine_points(start[i], end[i])
-        grid = build_sample_grids(pts, cams, cfg, resize_transform)
+        if fine_grid is not None:
+            grid = fine_grid[:, start[i, 0]:end[i, 0], start[i, 1]:end[i, 1], start[i, 2]:end[i, 2]].reshape(V, -1, 2)
+        else:
+            grid = build_sample_grids(spec.fine_points(start[i], end[i]), cams, cfg, resize_transform)
         d = (end[i] - start[i]).tolist()
         vals = bilinear_mean(heat, grid).view(J, d[0], d[1], d[2])
         s = (start[i] - tl[i]).tolist()
@@ -389,6 +432,7 @@ class Oracle:
         self.whole_pts = compute_grid(cfg.CAPTURE_SPEC.SPACE_SIZE, cfg.CAPTURE_SPEC.SPACE_CENTER,
                                       cfg.CAPTURE_SPEC.VOXELS_PER_AXIS)
         self._grids = {}
+        self._fine_grids = {}
         self._sd_cast = {}
         self.trace = {}
 
@@ -433,9 +477,12 @@ class Oracle:
             if int(mask[i].sum()) == 0:
                 per_frame.append(None)
                 continue
-            cams = self._cams(cameras, meta["seq"][i])
+            seq = meta["seq"][i]
+            cams = self._cams(cameras, seq)
+            if seq not in self._fine_grids:              # cached per sequence, like the reference (:104-106)
+                self._fine_grids[seq] = fine_sample_grid(self.spec, cfg, cams, resize_transform)
             cubes, offset, boxes = project_individual(self.spec, cfg, heatmaps[i], centers[i, mask[i]],
-                                                      cams, resize_transform)
+                                                      cams, resize_transform, self._fine_grids[seq])
             tri = triplane_max(cubes)
             feat = torch.stack(torch.chunk(p2p_net(sd, "joint_net.conv_net", tri.to(net_dtype)), 3), dim=0)
             pose, conf = soft_argmax(feat, self.spec.center_grid, cfg.NETWORK.BETA, net_dtype)
