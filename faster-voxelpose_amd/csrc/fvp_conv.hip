@@ -813,14 +813,19 @@ static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
 static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
+static const int kWinoWC1 = int(env_size("FVP_WINO_WC1", 0));        // diagnostics: 32-cout blocks for every layer
+// two independent 4-wave workgroups per CU (32 couts x 64 tiles each, <= 80 KB of LDS) instead of one 8-wave
+// workgroup: one workgroup's prologue / epilogue / barrier stalls overlap the other's MFMAs
+static const int kWinoHalf = int(env_size("FVP_WINO_HALF", 0));
+static const int kWinoNoResW = int(env_size("FVP_WINO_NO_RESW", 0)); // diagnostics: stream the weights of the 32-channel layers too
 
 // Shapes the Winograd kernel covers: 3x3, even H, W a power of two in [8, 64*4] with W/2 dividing
 // a wave's 32 tiles or vice versa.  Decided from the layer SHAPE only (never from the number of
 // planes), so a frame's result does not depend on the batch it is computed in.
 static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int* TN, int* TR) {
   if (h < 2 || (h & 1) || w < 8 || (w & (w - 1)) || (coutp != 32 && coutp % 64 != 0) || cinp % 4 != 0) return false;
-  *WC = coutp == 32 ? 1 : 2;
-  *WT = 8 / *WC;
+  *WC = (coutp == 32 || kWinoWC1 || kWinoHalf) ? 1 : 2;
+  *WT = (kWinoHalf ? 4 : 8) / *WC;
   const int tpr = w / 2, TT = 16 * *WT, per_plane = (h / 2) * tpr;
   if (TT % tpr != 0) return false;
   if (per_plane >= TT) {
@@ -835,17 +840,19 @@ static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int
   return true;
 }
 
-template <int WC, int WT, int CC, bool RES>
+template <int WC, int WT, int CC, bool RES, bool RESW = false>
 static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static LdsOptIn optin;
-  auto k = &k_conv_wino<WC, WT, CC, RES>;
+  auto k = &k_conv_wino<WC, WT, CC, RES, RESW>;
   if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), 160 * 1024)) return e;
-  hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL(k, grid, dim3(WC * WT * 64), lds, s, a);
   return launch_status();
 }
 template <int WC, int WT>
-static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, bool resw) {
   const bool res = a.flags & FVP_EPI_RES;
+  if (WC == 1 && WT == 8 && resw && a.CC == 8)
+    return res ? launch_wino2<1, 8, 8, true, true>(a, grid, lds, s) : launch_wino2<1, 8, 8, false, true>(a, grid, lds, s);
   if (a.CC == 8) return res ? launch_wino2<WC, WT, 8, true>(a, grid, lds, s) : launch_wino2<WC, WT, 8, false>(a, grid, lds, s);
   return res ? launch_wino2<WC, WT, 4, true>(a, grid, lds, s) : launch_wino2<WC, WT, 4, false>(a, grid, lds, s);
 }
@@ -879,31 +886,41 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   a.zeros = params;
   const int CBW = 32 * WC;
   // channels per chunk: 8 when it divides cinp and three slots fit, else 4
-  auto slot_bytes = [&](int cc, int* ni) {
+  // resident weights: one 32-cout block covers all couts and [cinp][32][16] fits beside the three input slots
+  const size_t resw_bytes = size_t(op.cinp) * CBW * 64;
+  const size_t budget = WC * WT == 4 ? std::min<size_t>(kWinoLdsBudget, 78 * 1024) : kWinoLdsBudget;   // two workgroups per CU
+  bool resw = WC == 1 && WT == 8 && op.coutp == 32 && op.cinp % 8 == 0 && resw_bytes <= 64 * 1024 && !kWinoNoResW;
+  auto slot_bytes = [&](int cc, int* ni, bool rw) {
     const size_t quads = size_t(cc) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1;
-    *ni = int((quads + 511) / 512);
-    return size_t(*ni) * 8192 + size_t(cc) * CBW * 64;
+    const size_t per_round = size_t(WC) * WT * 64;       // one 16-byte item per thread and round
+    *ni = int((quads + per_round - 1) / per_round);
+    return size_t(*ni) * per_round * 16 + (rw ? 0 : size_t(cc) * CBW * 64);
   };
   int CC = op.cinp % 8 == 0 ? 8 : 4, ni = 0;
-  size_t slot = slot_bytes(CC, &ni);
-  if (CC == 8 && (3 * slot + 64 > kWinoLdsBudget || ni > 4)) {
-    CC = 4;
-    slot = slot_bytes(CC, &ni);
+  size_t slot = slot_bytes(CC, &ni, resw);
+  if (resw && (3 * slot + resw_bytes + 64 > budget || ni > 4)) {
+    resw = false;
+    slot = slot_bytes(CC, &ni, false);
   }
-  if (3 * slot + 64 > kWinoLdsBudget || ni > 4) return FVP_ELIMIT;
+  if (CC == 8 && !resw && (3 * slot + 64 > budget || ni > 4)) {
+    CC = 4;
+    slot = slot_bytes(CC, &ni, false);
+  }
+  if (3 * slot + (resw ? resw_bytes : 0) + 64 > budget || ni > 4) return FVP_ELIMIT;
   a.CC = CC;
   a.wino_ni = ni;
   a.m_qpr = make_magic(op.w / 4 + 1);
   a.m_rpc = make_magic(TN * (a.TH + 2));
   a.m_thp = make_magic(a.TH + 2);
-  const size_t lds = 16 + 3 * slot;
+  const size_t lds = 16 + 3 * slot + (resw ? resw_bytes : 0);
   a.ysplit = op.coutp / CBW;
   a.nunits = a.tiles_y * ceil_div(planes, TN) * a.ysplit;
   a.m_ys = make_magic(a.ysplit);
   a.m_ty = make_magic(a.tiles_y);
-  dim3 grid(std::min(a.nunits, persistent_workgroups()), 1, 1);
+  dim3 grid(std::min(a.nunits, persistent_workgroups() * (WC * WT == 4 ? 2 : 1)), 1, 1);
   ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
-  return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s) : launch_wino<2, 4>(a, grid, lds, s);
+  if (WC * WT == 4) return launch_wino<1, 4>(a, grid, lds, s, false);
+  return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false);
 }
 
 // ConvTranspose(k2,s2) in the paired form: CB = 2*coutp/32 accumulator blocks (both column taps),
@@ -995,7 +1012,7 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   const int CBfull = op.coutp / 32;
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
   a.ablate = kAblate;
-  if (!tr && op.wino_off > 0 && !kNoWino) return plan_and_launch_wino(op, a, params, planes, s);
+  if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp) return plan_and_launch_wino(op, a, params, planes, s);
   // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
   // Large grids keep all couts in one workgroup (input tile staged once); small grids split
   // couts over blockIdx.y and shrink the pixel tile so that more CUs get work.
@@ -1109,7 +1126,7 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
       rc = launch_status();
     } else if (op.kind == FVP_OP_CONV || op.kind == FVP_OP_CONVT2) {
       float* pool_dst = nullptr;
-      if (op.kind == FVP_OP_CONV && op.wino_off > 0 && !kNoWino && !kNoPoolFuse) {
+      if (op.kind == FVP_OP_CONV && op.wino_off > 0 && op.cin == op.cinp && !kNoWino && !kNoPoolFuse) {
         for (int j = i + 1; j < nops && j < 64; ++j)
           if (ops[j].kind == FVP_OP_POOL2 && ops[j].src == op.dst && ops[j].h == op.h && ops[j].w == op.w &&
               ops[j].h > 1 && ops[j].cin == op.cout && ops[j].dst >= 0 && ops[j].dst < nbufs) {

@@ -26,6 +26,10 @@
 #ifndef FVP_WINO_IN_AUX
 #define FVP_WINO_IN_AUX 0
 #endif
+// column pass of the patch transform: 1 = packed adds (v_pk_add_f32), 0 = scalar adds
+#ifndef FVP_WINO_PK
+#define FVP_WINO_PK 1
+#endif
 
 namespace fvp {
 
@@ -36,7 +40,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   v03 = (t0 - t2, t1 - t3)   v12 = (t1 + t2, t2 - t1)
 // one packed add each (the half swaps and sign flips are operand modifiers of v_pk_add_f32).
 __device__ __forceinline__ void wino_cols(f32x2 E, f32x2 M, f32x2& v03, f32x2& v12) {
-#if defined(__AMDGCN__)
+#if defined(__AMDGCN__) && FVP_WINO_PK
   asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v03) : "v"(E), "v"(M));
   asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(M));
 #else
@@ -47,14 +51,20 @@ __device__ __forceinline__ void wino_cols(f32x2 E, f32x2 M, f32x2& v03, f32x2& v
 
 // CC = channels per LDS chunk (4 or 8, divides cinp): the steps of a chunk are unrolled so that
 // every weight read is `chunk base + immediate`.
-template <int WC, int WT, int CC, bool HAS_RES>
-__global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
+// RESW: the whole Winograd-domain weight tensor of the workgroup's cout block ([cinp][CBW][16], <= 64 KB)
+// stays resident in LDS behind the three input slots (loaded once per persistent workgroup) instead of
+// streaming through the slots chunk by chunk: for the 32-channel layers the weight chunks were more than
+// half of the LDS-DMA traffic of a unit.
+template <int WC, int WT, int CC, bool HAS_RES, bool RESW = false>
+__global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
-  static_assert(WC * WT == 8, "8 waves");
+  constexpr int NWV = WC * WT;                       // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+  static_assert(NWV == 8 || NWV == 4, "4 or 8 waves");
   static_assert(CC == 4 || CC == 8, "chunk");
   constexpr int CBW = 32 * WC;
-  constexpr int WS_SZ = CC * CBW * 16;               // floats of one weight chunk
-  constexpr int NW = CC * WC / 4;                    // weight DMA instructions per wave per chunk
+  constexpr int WCH = CC * CBW * 16;                 // floats of one weight chunk
+  constexpr int WS_SZ = RESW ? 0 : WCH;              // ... streamed through a slot
+  constexpr int NW = RESW ? 0 : CC * WC * 2 / NWV;   // weight DMA instructions per wave per chunk
   constexpr int S = CC / 4;                          // steps (4 channels) per chunk
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int k4 = lane >> 4, l15 = lane & 15;
@@ -62,7 +72,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   const int THp = a.TH + 2, W = a.W, WP = W + 4;
   const int plane_sz = THp * WP;
   const int CS = a.TN * plane_sz;
-  const int xs_sz = a.wino_ni * 2048;                // input slot, padded to whole DMA rounds (floats)
+  const int xs_sz = a.wino_ni * (NWV * 256);         // input slot, padded to whole DMA rounds (floats)
   const int buf_sz = xs_sz + WS_SZ;
 
   // Persistent workgroups: unit u = (plane group, row band, cout block); workgroup b walks
@@ -91,7 +101,10 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   const int swz = (l15 >> 2) & 3;
   int aoff[4];                                       // cout block cb adds 16 rows = 256 floats
 #pragma unroll
-  for (int xi = 0; xi < 4; ++xi) aoff[xi] = xs_sz + ((k4 * CBW + wc * 32 + l15) * 4 + (xi ^ swz)) * 4;
+  for (int xi = 0; xi < 4; ++xi) aoff[xi] = ((k4 * CBW + wc * 32 + l15) * 4 + (xi ^ swz)) * 4;
+  const float* const wres = smem + 4 + 3 * buf_sz;   // RESW: resident weights [cinp][CBW][16]
+  // first weight float of chunk k living in slot `slot` (streamed) or in the resident copy
+  auto wchunk = [&](const float* slot, int k) { return RESW ? wres + k * WCH : slot + xs_sz; };
 
   f32x4 acc[2][16];
 #pragma unroll
@@ -114,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   int rel_off[kMaxIn], meta[kMaxIn];
 #pragma unroll
   for (int j = 0; j < kMaxIn; ++j) {
-    const int it = (wave + 8 * j) * 64 + lane;
+    const int it = (wave + NWV * j) * 64 + lane;
     rel_off[j] = 0;
     meta[j] = -1;                                    // zero page: margins, padding items
     if (it < nin) {
@@ -124,50 +137,69 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       const int n = fdiv(rem, a.m_thp), ry = rem - n * THp;
       if (qd > 0 && ci < CC) {
         rel_off[j] = (n * a.cin + ci) * HW + (ry - 1) * W + 4 * (qd - 1);
-        meta[j] = ry | (n << 8) | (ci << 16);
+        meta[j] = ry | (n << 8);
       }
     }
   }
-  // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
-  auto stage = [&](int su, int k, int boff) {
-    const int st = fdiv(su, a.m_ys), sy = su - st * a.ysplit;
+  // ---- DMA cursor (unit su, chunk sk).  Everything that depends on the unit only - the base pointers
+  // and which of this lane's items fall inside the image - is computed when the cursor ENTERS a unit;
+  // per chunk a DMA item then costs a pointer add and a select (the address code used to be ~600
+  // instructions per chunk and wave, issued between the MFMA bursts of the other wave of the SIMD).
+  // The host guarantees cin % CC == 0 (no partial channel chunks).
+  int su = u, sk = 0;
+  const float* ubase = a.src;                        // uniform: the cursor unit's (plane group, row band), channel 0
+  const float* gwbase = a.wts;                       // uniform: the cursor unit's cout block, channel 0
+  unsigned okmask = 0;                               // per lane: bit j <=> item j reads the image, else the zero page
+  auto enter_unit = [&](int su_) {
+    const int st = fdiv(su_, a.m_ys), sy = su_ - st * a.ysplit;
     const int spg = fdiv(st, a.m_ty), sty = st - spg * a.tiles_y;
     const int splane0 = spg * a.TN, sy0 = sty * a.TH;
+    ubase = a.src + size_t(splane0) * a.cin * HW + sy0 * W;
+    gwbase = a.wts + size_t(sy) * (CBW * 16);
+    okmask = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxIn; ++j) {
+      const int ry = meta[j] & 255, n = (meta[j] >> 8) & 255;
+      const bool ok = meta[j] >= 0 && unsigned(sy0 + ry - 1) < unsigned(a.H) && splane0 + n < a.planes;
+      okmask |= ok ? (1u << j) : 0u;
+    }
+  };
+  const size_t in_step = size_t(CC) * HW, w_step = size_t(CC) * a.coutp * 16;
+  // this lane's weight item j: channel ci0 + j * DCI of the chunk, quad qd0 of the cout block's row
+  constexpr int DCI = NWV * 64 / (CBW * 4);
+  const int wit = wave * 64 + lane;
+  const size_t woff0 = size_t(wit / (CBW * 4)) * a.coutp * 16 + 4 * (wit % (CBW * 4));
+  const size_t wdj = size_t(DCI) * a.coutp * 16;
+  // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
+  auto stage = [&](int k, int boff) {
     float* xs = smem + 4 + boff;
     float* ws = xs + xs_sz;
-    const int c0 = k * CC;
-    const float* src_unit = a.src + (size_t(splane0) * a.cin + c0) * HW + sy0 * W;
+    const float* bk = ubase + size_t(k) * in_step;
 #pragma unroll
     for (int j = 0; j < kMaxIn; ++j) {
       if (j < a.wino_ni) {
-        const int g = wave + 8 * j;
-        const int ry = meta[j] & 255, n = (meta[j] >> 8) & 255, ci = meta[j] >> 16;
-        const bool ok = meta[j] >= 0 && unsigned(sy0 + ry - 1) < unsigned(a.H) && splane0 + n < a.planes &&
-                        c0 + ci < a.cin;
-        const float* src = ok ? src_unit + rel_off[j] : a.zeros;
+        const int g = wave + NWV * j;
+        const float* src = ((okmask >> j) & 1u) ? bk + rel_off[j] : a.zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, FVP_WINO_IN_AUX);
       }
     }
-    const float* gw = a.wts + size_t(sy) * (CBW * 16) + size_t(c0) * a.coutp * 16;
+    const float* wk = gwbase + size_t(k) * w_step + woff0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const int g = wave + 8 * j;
-      const int it = g * 64 + lane;
-      const int ci = it / (CBW * 4), qd = it - ci * (CBW * 4);
-      const float* src = gw + size_t(ci) * a.coutp * 16 + 4 * qd;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      const int g = wave + NWV * j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + j * wdj),
                                        (__attribute__((address_space(3))) void*)(ws + g * 256), 16, 0, 0);
     }
   };
-  // cursor of the chunk stream the DMA follows (unit, chunk)
-  int su = u, sk = 0;
+  enter_unit(su);
   auto stage_next = [&](int boff) {
     if (su >= nunits) return false;
-    stage(su, sk, boff);
+    stage(sk, boff);
     if (++sk == nchunks) {
       sk = 0;
       su = next_unit(su + G);
+      if (su < nunits) enter_unit(su);
     }
     return true;
   };
@@ -176,10 +208,10 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   float4 av[2][4];
   f32x2 dM[4], dE[4];                                // patch rows as pairs (d1,d2) and (d0,d3)
   f32x2 v03[4], v12[4];                              // V[xi][0],V[xi][3] and V[xi][1],V[xi][2]
-  auto fetch_a = [&](int cb, const float* base, int s) {      // base = chunk slot, s = step in chunk
+  auto fetch_a = [&](int cb, const float* wbase, int s) {     // wbase = weights of the chunk, s = step in chunk
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi)
-      av[cb][xi] = *reinterpret_cast<const float4*>(base + aoff[xi] + (s * 4 * CBW * 16 + cb * 256));
+      av[cb][xi] = *reinterpret_cast<const float4*>(wbase + aoff[xi] + (s * 4 * CBW * 16 + cb * 256));
   };
   auto fetch_d = [&](const float* base, int s, int wp) {
     const float* xs = base + poff + s * 4 * CS;
@@ -208,6 +240,15 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
 
   // ---- three chunk slots: chunk g+2 streams in while chunk g is consumed
   const bool dma = !(a.ablate & 1);
+  if (RESW) {                                        // cinp * CBW * 4 quads, NWV * 64 per round
+    const int rounds = (a.cinp * CBW * 4) / (NWV * 64);
+    for (int j = 0; j < rounds; ++j) {
+      const int g = wave + NWV * j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wts + size_t(g * 64 + lane) * 4),
+                                       (__attribute__((address_space(3))) void*)(smem + 4 + 3 * buf_sz + g * 256), 16, 0, 0);
+    }
+    if (!dma) wait_vmcnt(0);
+  }
   if (dma) {
     stage_next(0);
     const bool second = stage_next(buf_sz);
@@ -215,7 +256,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
   }
   __syncthreads();
   int cur_off = 0;
-  fetch_a(0, smem + 4, 0);
+  fetch_a(0, wchunk(smem + 4, 0), 0);
   fetch_d(smem + 4, 0, WP);
   while (true) {
   for (int k = 0; k < nchunks; ++k) {
@@ -231,7 +272,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       // ---- half-step 0: patch transform, cout block 0
       __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): av[0] and the patch have landed
       __builtin_amdgcn_sched_barrier(0);
-      fetch_a(1, cur, s);
+      fetch_a(1, wchunk(cur, k), s);
       __builtin_amdgcn_sched_barrier(0);             // issue the reads now: left alone hipcc sinks them below the MFMAs
       f32x2 tM[4], tE[4];
       transform_rows(tM, tE);
@@ -245,14 +286,14 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < S) {
-        fetch_a(0, cur, s + 1);
+        fetch_a(0, wchunk(cur, k), s + 1);
       } else {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
         // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
         if (dma) wait_vmcnt(more ? nps : 0);
         __syncthreads();
         if (k + 1 < nchunks) {                       // (a unit's last chunk: the epilogue needs the registers)
-          fetch_a(0, nxt, 0);
+          fetch_a(0, wchunk(nxt, k + 1), 0);
           fetch_d(nxt, 0, wp);
         }
       }
@@ -343,7 +384,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wino(ConvArgs a) {
       for (int r = 0; r < 4; ++r) acc[cb][p][r] = 0.0f;
   u = next_unit(u + G);
   if (u >= nunits) break;
-  fetch_a(0, smem + 4 + cur_off, 0);
+  fetch_a(0, wchunk(smem + 4 + cur_off, 0), 0);
   fetch_d(smem + 4 + cur_off, 0, WP);
   }
 }

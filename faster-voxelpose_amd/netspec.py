@@ -58,10 +58,12 @@ class ParamTree(nn.Module):
         raise RuntimeError("ParamTree holds parameters only")
 
 
-def winograd_shape(kh, kw, h, w, cinp, coutp):
+def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None):
     """3x3 layers the F(2x2,3x3) kernel covers (the same rule as wino_tiling() in
     csrc/fvp_conv.hip): decided from the layer shape alone, never from the batch."""
     if (kh, kw) != (3, 3) or h < 2 or h % 2 or w < 8 or w & (w - 1) or (coutp != 32 and coutp % 64) or cinp % 4:
+        return False
+    if cin is not None and cin != cinp:          # whole channel chunks only (no padded input channels)
         return False
     wt = 8 if coutp == 32 else 4
     tpr, tt, per_plane = w // 2, 16 * wt, (h // 2) * (w // 2)
@@ -198,7 +200,7 @@ class StackSpec:
                 off += _round_up(cinp * o["kh"] * o["kw"] * coutp, 4)
                 e_off = off
                 off += _round_up(3 * coutp, 4)
-                if o["kind"] == capi.OP_CONV and winograd_shape(o["kh"], o["kw"], o["h"], o["w"], cinp, coutp):
+                if o["kind"] == capi.OP_CONV and winograd_shape(o["kh"], o["kw"], o["h"], o["w"], cinp, coutp, o["cin"]):
                     wino_off = off
                     off += cinp * coutp * 16
                 if (o["kind"] == capi.OP_CONV and (o["kh"], o["kw"]) == (7, 7) and o["cout"] <= 16

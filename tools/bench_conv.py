@@ -13,6 +13,9 @@ import torch  # noqa: E402
 
 import fvp_synthetic as S  # noqa: E402
 from faster_voxelpose_amd import _capi as capi  # noqa: E402
+
+if os.environ.get("FVP_LIB"):          # diagnostics only: a variant built by tools/build_variant.sh
+    capi.LIB_PATH = os.path.abspath(os.environ["FVP_LIB"])
 from faster_voxelpose_amd.engine import _ptr  # noqa: E402
 from faster_voxelpose_amd.models import faster_voxelpose as FV  # noqa: E402
 
