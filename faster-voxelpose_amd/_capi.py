@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfvp_hip.so"
-ABI_VERSION = 2            # include/fvp.h FVP_ABI_VERSION
+ABI_VERSION = 3            # include/fvp.h FVP_ABI_VERSION
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 FVP_CAM_FLOATS = 24
@@ -59,7 +59,7 @@ SIGNATURES = {
     "fvp_person_boxes": [_P, _I, _P, _P, _P, _P, _P],
     "fvp_project_individual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _G, _P, _P],
     "fvp_triplane_max": [_P, _P, _I, _I, _I, _P],
-    "fvp_project_individual_triplane": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _G, _P, _I, _P],
+    "fvp_project_individual_triplane": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _G, _P, _I, _P, _P],
     "fvp_conv_stack_run": [C.POINTER(FvpConvOp), _I, _P, C.POINTER(_P), _I, _I, _P, _I, _P],
     "fvp_conv_stack_run_fused_1d": [C.POINTER(FvpConvOp), _I, _P, _P, _P, _I, _P],
     "fvp_pack_conv": [_P, _P, _P, _P, _P, _P, _F, _I, C.POINTER(FvpConvOp), _P, _P],

@@ -9,7 +9,7 @@ objs=()
 for s in "${srcs[@]}"; do
   o="${here}/${s%.hip}.o"
   if [[ ! -f "$o" || "$o" -ot "${here}/$s" || "$o" -ot "${here}/fvp_common.h" || "$o" -ot "${here}/fvp_geom.h" \
-        || "$o" -ot "${here}/../../include/fvp.h" || "$o" -ot "${here}/fvp_conv_wino.h" ]]; then
+        || "$o" -ot "${here}/../../include/fvp.h" || "$o" -ot "${here}/fvp_conv_wino.h" || "$o" -ot "${here}/fvp_project_lds.h" ]]; then
     # geometry / proposal / fusion code mirrors the reference's separately-rounded fp32 ops:
     # no fma contraction there (HIP's __fmul_rn/__fadd_rn are plain operators); the MFMA conv
     # file keeps the default.

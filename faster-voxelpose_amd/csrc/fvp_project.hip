@@ -304,14 +304,25 @@ template <int NVL>
 __global__ void __launch_bounds__(1024)
 k_project_whole_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cams,
                   const int* __restrict__ frame_set, const float* __restrict__ ax, const float* __restrict__ ay,
-                  const float* __restrict__ az, int X, int Y, int Z, FvpGeom g, float* __restrict__ cubes,
-                  float* __restrict__ zmax) {
+                  const float* __restrict__ az, int X, int Y, int Z, int B, int nblk, FvpGeom g,
+                  float* __restrict__ cubes, float* __restrict__ zmax) {
   __shared__ float sm[16 * NVL][256];
   const int cpb = 256 / Z;
-  const int b = blockIdx.y;
+  // 1-D grid of B * nblk workgroups.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with
+  // its own L2), so with B % 8 == 0 frame f is pinned to XCD f % 8: an XCD's L2 then holds the heatmaps of
+  // one frame at a time instead of all B (HBM-side fetch was 3.5x the algorithmic bytes without it).
+  int b, bxi;
+  if (B % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    b = xcd + 8 * (j / nblk);
+    bxi = j % nblk;
+  } else {
+    b = blockIdx.x / nblk;
+    bxi = blockIdx.x % nblk;
+  }
   const int t = threadIdx.x, q = t & 3, vl = t >> 2;           // vl = voxel inside the workgroup
   const int cl_ = vl / Z, z = vl - cl_ * Z;
-  const int col = blockIdx.x * cpb + cl_;
+  const int col = bxi * cpb + cl_;
   const int ncol = X * Y;
   const bool active = cl_ < cpb && col < ncol;
   const int J = g.J, JP = g.JP;
@@ -367,7 +378,7 @@ k_project_whole_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cam
     __syncthreads();
     for (int item = t; item < cpb * J; item += 1024) {
       const int c = item / cpb, k = item - c * cpb;
-      const int cc = blockIdx.x * cpb + k;
+      const int cc = bxi * cpb + k;
       if (cc < ncol) {
         float m = sm[c][k * Z];
         for (int zz = 1; zz < Z; ++zz) m = fmaxf(m, sm[c][k * Z + zz]);
@@ -515,6 +526,10 @@ k_project_triplane(const float* __restrict__ heat_cl, const Cam* __restrict__ ca
   }
 }
 
+}  // namespace fvp
+#include "fvp_project_lds.h"
+namespace fvp {
+
 // z-max of materialised cubes: one thread per (b,j,x,y) column.
 __global__ void __launch_bounds__(256) k_zmax(const float* __restrict__ cubes, float* __restrict__ zmax, long n, int Z) {
   const long i = long(blockIdx.x) * 256 + threadIdx.x;
@@ -624,12 +639,13 @@ extern "C" int fvp_project_whole(const float* heat_cl, const float* cams, const 
   static const bool no_quad = getenv("FVP_WHOLE_NO_QUAD") != nullptr;
   const int nvl = ceil_div(g->JP, 16);
   if (!no_quad && nvl <= 2) {
+    const int nblk = ceil_div(X * Y, cpb);
     if (nvl == 1)
-      hipLaunchKernelGGL(k_project_whole_q<1>, dim3(ceil_div(X * Y, cpb), B), dim3(1024), 0, as_stream(s), heat_cl,
-                         reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, *g, cubes, zmax);
+      hipLaunchKernelGGL(k_project_whole_q<1>, dim3(nblk * B), dim3(1024), 0, as_stream(s), heat_cl,
+                         reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, B, nblk, *g, cubes, zmax);
     else
-      hipLaunchKernelGGL(k_project_whole_q<2>, dim3(ceil_div(X * Y, cpb), B), dim3(1024), 0, as_stream(s), heat_cl,
-                         reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, *g, cubes, zmax);
+      hipLaunchKernelGGL(k_project_whole_q<2>, dim3(nblk * B), dim3(1024), 0, as_stream(s), heat_cl,
+                         reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, B, nblk, *g, cubes, zmax);
     return launch_status();
   }
 #define CALL(NV)                                                                                              \
@@ -699,9 +715,10 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
                                                const int32_t* person_frame, const uint8_t* person_valid,
                                                const int32_t* boxes, const float* fx, const float* fy,
                                                const float* fz, const int32_t* fine, int C, int nP, const FvpGeom* g,
-                                               float* planes, int persons_per_frame, fvp_stream_t s) {
+                                               float* planes, int persons_per_frame, const float* fine_grid,
+                                               fvp_stream_t s) {
   FVP_REQUIRE(heat_cl && cams && frame_set && person_frame && boxes && fx && fy && fz && planes && nP >= 0);
-  (void)fine;
+  FVP_REQUIRE(!fine_grid || fine);
   if (int e = check_geom(g)) return e;
   if (int e = check_cube(C)) return e;
   if (nP == 0) return 0;
@@ -711,6 +728,33 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   const int chunks = ceil_div(C * C, 256);
   const int nvl = ceil_div(g->JP, 16);
   ProfScope ps(FVP_K_PROJECT_TRIPLANE, as_stream(s));
+  // default: heatmap footprint staged in LDS (fvp_project_lds.h); FVP_TRIPLANE_GATHER=1 selects the first fused
+  // kernel (every tap through the texture path) for comparison
+  static const bool gather = getenv("FVP_TRIPLANE_GATHER") != nullptr;
+  if (!gather && nvl <= 2) {
+    const int nbx = ceil_div(C, kBX), nby = ceil_div(C, kBY);
+    // two tiles per workgroup, two workgroups (512 threads, <= 128 VGPRs) per CU: 4 x 36 KB + state
+    const int cap_px = int((36 * 1024) / (size_t(g->JP) * 4));
+    FVP_LIMIT(cap_px >= kBX * kBY + (kBX + kBY) * kBZ);
+    const size_t lds = 2 * size_t(cap_px) * g->JP * 4 + 64;
+    const int F0 = fine_grid ? fine[0] : 0, F1 = fine_grid ? fine[1] : 0, F2 = fine_grid ? fine[2] : 0;
+#define CALL(NVL_, CACHED_)                                                                                        \
+  {                                                                                                                \
+    static LdsOptIn optin;                                                                                         \
+    auto k = &k_project_triplane_lds<NVL_, CACHED_>;                                                               \
+    if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds)) return e;                                \
+    hipLaunchKernelGGL(k, dim3(nbx * nby * nP), dim3(kTriThreads), lds, as_stream(s), heat_cl,                     \
+                       reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, \
+                       nP, nbx, nby, ppf, cap_px, *g, fine_grid, F0, F1, F2, planes);                              \
+  }
+    if (nvl == 1) {
+      if (fine_grid) CALL(1, true) else CALL(1, false)
+    } else {
+      if (fine_grid) CALL(2, true) else CALL(2, false)
+    }
+#undef CALL
+    return launch_status();
+  }
   if (nvl == 1) {
     auto k = &k_project_triplane<1>;
     hipLaunchKernelGGL(k, dim3(chunks * nP), dim3(1024), 0, as_stream(s), heat_cl, reinterpret_cast<const Cam*>(cams),

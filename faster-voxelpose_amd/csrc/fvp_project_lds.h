@@ -1,0 +1,367 @@
+// Fused per-person back-projection + xy/xz/yz maxima with the heatmap footprint STAGED IN LDS
+// (included by fvp_project.hip).  Replaces project_individual.ProjectLayer.forward :124-134 +
+// joint_localization_net.py:80-81, same arithmetic per sample as every other projection kernel
+// (project_norm / bilinear weights / tap order / view-ordered sum), hence bit-equal planes.
+//
+// Why: one person's window (~40 x 40 x 64 voxels x 5 views x 4 taps) reads 335 MB of taps out of a
+// footprint of ~1.4 MB: neighbouring voxels re-read the same heatmap pixels ~240 times.  The first
+// fused kernel gathered every tap through the texture path and sat at the L1 line rate (36 of
+// 39 TB/s, 738 us for 80 people).  Here a workgroup owns a block of 8 x 8 x 32 voxels; per view it
+//   1. projects the block's voxels (lane q of a voxel quad projects voxels q, q+4 and shares the
+//      result with DPP quad_perm), reduces the bounding rectangle of their taps over the workgroup,
+//   2. copies that rectangle of the channels-last heatmap (~14 x 44 px x JP floats) into LDS with the
+//      LDS-DMA (coalesced 16-byte items, no VGPRs),
+//   3. samples all 2048 voxels from LDS (ds_read_b128: the four lanes of a voxel read the 64
+//      contiguous bytes of a pixel),
+// accumulating the view sum in registers in view order.  After the last view: divide, clamp, and
+// reduce the block's values into its 8x8 (xy), 8x32 (xz) and 8x32 (yz) cells through LDS integer
+// atomicMax, then into the global planes with integer atomicMax (values are clamped to [0,1]:
+// non-negative floats order like ints; the planes are pre-zeroed; zeros are skipped).
+//
+// Two workgroups (1024 threads, <= 76 KB of LDS) share a CU: one samples while the other waits for
+// its DMA.  A rectangle that does not fit the tile falls back to global gathers for that view.
+#pragma once
+#include <climits>
+
+namespace fvp {
+
+struct TapL {      // tap descriptor of one (voxel, view), relative to the staged rectangle
+  int base;        // float offset of the nw tap's pixel (clamped into the rectangle), channel 0, in the LDS tile
+  int dx, dy;      // float offsets nw -> ne and nw -> sw (0 where the neighbour is clamped onto the same pixel)
+  float w[4];      // bilinear weights, ZERO for taps outside the image (0 * pixel = +0: the reference's zero padding)
+};
+
+template <int SRC>
+__device__ __forceinline__ TapL quad_bcast_l(const TapL& t) {
+  TapL r;
+  r.base = quad_bcast_i<SRC>(t.base);
+  r.dx = quad_bcast_i<SRC>(t.dx);
+  r.dy = quad_bcast_i<SRC>(t.dy);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.w[k] = __int_as_float(quad_bcast_i<SRC>(__float_as_int(t.w[k])));
+  return r;
+}
+
+// pixel of the nw tap and the bilinear weights of a normalised coordinate (same expressions as bilinear_taps)
+__device__ __forceinline__ void tap_origin(float gx, float gy, int W, int H, int& x0, int& y0, float (&w)[4], int& inside) {
+  const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * float(W - 1));
+  const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * float(H - 1));
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float x1f = __fadd_rn(x0f, 1.0f), y1f = __fadd_rn(y0f, 1.0f);
+  w[0] = __fmul_rn(__fsub_rn(x1f, ix), __fsub_rn(y1f, iy));
+  w[1] = __fmul_rn(__fsub_rn(ix, x0f), __fsub_rn(y1f, iy));
+  w[2] = __fmul_rn(__fsub_rn(x1f, ix), __fsub_rn(iy, y0f));
+  w[3] = __fmul_rn(__fsub_rn(ix, x0f), __fsub_rn(iy, y0f));
+  x0 = int(x0f);
+  y0 = int(y0f);
+  const bool x0in = x0 >= 0 && x0 < W, x1in = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool y0in = y0 >= 0 && y0 < H, y1in = y0 + 1 >= 0 && y0 + 1 < H;
+  inside = (x0in && y0in ? 1 : 0) | (x1in && y0in ? 2 : 0) | (x0in && y1in ? 4 : 0) | (x1in && y1in ? 8 : 0);
+}
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// max over the 16 lanes of a DPP row (all lanes of the row receive it)
+__device__ __forceinline__ int row_max(int v) {
+  v = imax(v, dpp_i<0xB1>(v));        // quad_perm [1,0,3,2]
+  v = imax(v, dpp_i<0x4E>(v));        // quad_perm [2,3,0,1]
+  v = imax(v, dpp_i<0x141>(v));       // row_half_mirror
+  v = imax(v, dpp_i<0x140>(v));       // row_mirror
+  return v;
+}
+
+#ifndef FVP_TRI_BZ
+#define FVP_TRI_BZ 32
+#endif
+constexpr int kBX = 8, kBY = 4, kBZ = FVP_TRI_BZ;   // voxel block of a workgroup
+constexpr int kVPT = kBZ / 4;                  // voxels per thread: z = zs + 4 i
+constexpr int kOwn = kVPT / 4;                 // voxels a lane projects per view (i = q + 4 k)
+constexpr int kTriThreads = kBX * kBY * 4 * 4; // (x, y, zs) slots x 4 channel-quad lanes = 512
+
+// CACHED: sampling coordinates come from the per-sequence cache `fgrid` ([nsets][V][F0*F1*F2][2], the reference's
+// cached grid) instead of being recomputed: 2 coalesced 8-byte loads per lane and view replace ~230 VALU
+// instructions (the projection was ~45 % of the kernel's VALU work).
+template <int NVL, bool CACHED>   // NVL = channel quads per lane: ceil(JP/16)
+__global__ void __launch_bounds__(kTriThreads, NVL == 1 ? 4 : 2)     // NVL 1: <= 128 VGPRs, two workgroups per CU
+k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
+                       const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
+                       const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
+                       const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, int cap_px, FvpGeom g,
+                       const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  // LDS: two tiles of cap_px * JP floats (view v lives in tile v & 1; tile 0 is aliased by the block's plane
+  // cells after the last view) | 3 x 4 ints of rectangle state (view v uses slot v % 3)
+  constexpr int NT = kTriThreads;
+  const int J = g.J, JP = g.JP, CC = C * C, V = g.V, W = g.W, H = g.H;
+  const int tile_sz = cap_px * JP;
+  int* rect = reinterpret_cast<int*>(smem + 2 * size_t(tile_sz));        // [3][4]: -minx, maxx, -miny, maxy
+  // ---- block id -> (person, x block, y block); frame-major per XCD when the frame count allows it
+  int p, blk;
+  {
+    const int id = blockIdx.x;
+    const int bpp = nbx * nby, bpf = ppf * bpp;
+    const int nframes = nP / ppf;
+    if (nframes % 8 == 0) {
+      const int xcd = id & 7, j = id >> 3;
+      const int frame = xcd + 8 * (j / bpf), r = j % bpf;
+      p = frame * ppf + r / bpp;
+      blk = r % bpp;
+    } else {
+      p = id / bpp;
+      blk = id % bpp;
+    }
+  }
+  if (person_valid && !person_valid[p]) return;
+  const int* bx = boxes + p * 9;
+  const int tl0 = bx[0], tl1 = bx[1], tl2 = bx[2];
+  const int s0 = bx[3], s1 = bx[4], s2 = bx[5], e0 = bx[6], e1 = bx[7], e2 = bx[8];
+  if (s0 >= e0 || s1 >= e1 || s2 >= e2) return;
+  const int xb = blk / nby, yb = blk - xb * nby;
+  const int gx0 = s0 + xb * kBX, gy0 = s1 + yb * kBY;                   // blocks are aligned to the window start
+  if (gx0 >= e0 || gy0 >= e1) return;
+
+  const int t = threadIdx.x, q = t & 3, lane = t & 63, wave = t >> 6;
+  const int slot = t >> 2, zs = slot & 3, yy = (slot >> 2) & (kBY - 1), xx = slot / (4 * kBY);
+  const int gxi = gx0 + xx, gyi = gy0 + yy;                              // fine-grid indices of this thread's column
+  const bool col_in = gxi < e0 && gyi < e1;
+  const int b = person_frame[p];
+  const size_t view_stride = size_t(H) * W * JP;
+  const float* frame = heat_cl + size_t(b) * V * view_stride;
+  const Cam* cm = cams + size_t(frame_set[b]) * V;
+  const float wx = col_in ? fx[gxi] : 0.0f, wy = col_in ? fy[gyi] : 0.0f;
+  const size_t nfine = size_t(F0) * F1 * F2;
+  // cached coordinates of this thread's column (z = 0) in view 0 of the frame's camera set
+  const float2* gcol = CACHED ? reinterpret_cast<const float2*>(fgrid) + size_t(frame_set[b]) * V * nfine +
+                                    (size_t(col_in ? gxi : 0) * F1 + (col_in ? gyi : 0)) * F2
+                              : nullptr;
+  float* pxy = planes + (size_t(p) * 3 + 0) * J * CC;
+  float* pxz = planes + (size_t(p) * 3 + 1) * J * CC;
+  float* pyz = planes + (size_t(p) * 3 + 2) * J * CC;
+  const float nv = float(V);
+  const int qn = JP >> 2;                                                // channel quads per pixel
+  const unsigned m_qn = unsigned((1ull << 32) / unsigned(qn)) + 1u;
+
+  // this lane's two voxels (i = q and q + 4) of view v: projection, tap origin; contribution to view v's rectangle
+  struct Own { int xy[kOwn]; int inside[kOwn]; float w[kOwn][4]; };
+  // CACHED: coordinates of view v are loaded one iteration ahead (load_coords) so their latency hides behind
+  // the sampling of the previous view
+  float2 crd[kOwn];
+  auto load_coords = [&](int v, int gz0) {
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      const int gzi = gz0 + zs + 4 * (q + 4 * k);
+      crd[k] = gcol[size_t(v) * nfine + (gzi < F2 ? gzi : F2 - 1)];
+    }
+  };
+  auto project = [&](int v, int gz0, Own& o) {
+    int mnx = INT_MIN, mxx = INT_MIN, mny = INT_MIN, mxy = INT_MIN;     // (-min, max) pairs
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      const int gzi = gz0 + zs + 4 * (q + 4 * k);
+      const bool vin = col_in && gzi < e2;
+      o.inside[k] = 0;
+      o.xy[k] = 0;
+      o.w[k][0] = o.w[k][1] = o.w[k][2] = o.w[k][3] = 0.0f;
+      if (vin) {
+        float sx, sy;
+        if (CACHED) {
+          sx = crd[k].x;
+          sy = crd[k].y;
+        } else {
+          project_norm(cm[v], g, wx, wy, fz[gzi], sx, sy);
+        }
+        int x0, y0;
+        tap_origin(sx, sy, W, H, x0, y0, o.w[k], o.inside[k]);
+        o.xy[k] = int((unsigned(y0) << 16) | (unsigned(x0) & 0xffffu));
+        if (o.inside[k]) {
+          mnx = imax(mnx, -imax(x0, 0)); mxx = imax(mxx, imin(x0 + 1, W - 1));
+          mny = imax(mny, -imax(y0, 0)); mxy = imax(mxy, imin(y0 + 1, H - 1));
+        }
+      }
+    }
+    mnx = row_max(mnx); mxx = row_max(mxx); mny = row_max(mny); mxy = row_max(mxy);
+    if ((lane & 15) == 0 && mxx != INT_MIN) {
+      int* rc = rect + 4 * (v % 3);
+      atomicMax(&rc[0], mnx); atomicMax(&rc[1], mxx); atomicMax(&rc[2], mny); atomicMax(&rc[3], mxy);
+    }
+  };
+  struct Rect { int x0, y0, w, h, pitch; bool any, staged; };
+  auto read_rect = [&](int v) {
+    const int* rc = rect + 4 * (v % 3);
+    // workgroup-uniform values: keep them in scalar registers
+    const int c0 = __builtin_amdgcn_readfirstlane(rc[0]), c1 = __builtin_amdgcn_readfirstlane(rc[1]);
+    const int c2 = __builtin_amdgcn_readfirstlane(rc[2]), c3 = __builtin_amdgcn_readfirstlane(rc[3]);
+    Rect r;
+    r.any = c1 != INT_MIN;                                               // some tap of the block hits this view's image
+    r.x0 = r.any ? -c0 : 0;
+    r.y0 = r.any ? -c2 : 0;
+    r.w = r.any ? c1 - r.x0 + 1 : 0;
+    r.h = r.any ? c3 - r.y0 + 1 : 0;
+    r.pitch = r.w | 1;                                                   // odd pixel pitch: rows start in different bank quarters
+    r.staged = r.any && r.h * r.pitch <= cap_px;
+    return r;
+  };
+  // rectangle -> LDS tile, rows of pitch * JP floats.  A wave copies rows wave, wave + NW, ...: one LDS-DMA
+  // instruction per 64 quads of a row (lane = quad, so no index division; the pad column re-reads the last pixel)
+  auto issue_dma = [&](int v, const Rect& r) {
+    if (!r.staged) return;
+    float* tile = smem + (v & 1) * tile_sz;
+    const float* plane = frame + size_t(v) * view_stride + (size_t(r.y0) * W + r.x0) * JP;
+    const int pq = r.pitch * qn;                                         // quads per tile row
+    for (int c0 = 0; c0 < pq; c0 += 64) {
+      const int col = c0 + lane;
+      int px = qn == 4 ? col >> 2 : (qn == 1 ? col : int(__umulhi(unsigned(col), m_qn)));
+      const int cq = col - px * qn;
+      px = px < r.w ? px : r.w - 1;
+      const float* src0 = plane + size_t(px) * JP + 4 * cq;
+      for (int row = wave; row < r.h; row += NT / 64) {
+        if (col < pq)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + size_t(row) * W * JP),
+                                           (__attribute__((address_space(3))) void*)(tile + size_t(row * pq + c0) * 4), 16, 0, 0);
+      }
+    }
+  };
+  // descriptor of own voxel k relative to view v's rectangle (staged) or to the global plane (fallback: pitch = W)
+  auto finish = [&](const Own& o, int k, const Rect& r) {
+    TapL d;
+    const int x0 = (o.xy[k] << 16) >> 16, y0 = o.xy[k] >> 16;
+    const int rx0 = r.staged ? r.x0 : 0, ry0 = r.staged ? r.y0 : 0;
+    const int rx1 = r.staged ? r.x0 + r.w - 1 : W - 1, ry1 = r.staged ? r.y0 + r.h - 1 : H - 1;
+    const int pitch = r.staged ? r.pitch : W;
+    const int cx0 = imin(imax(x0, rx0), rx1), cx1 = imin(imax(x0 + 1, rx0), rx1);
+    const int cy0 = imin(imax(y0, ry0), ry1), cy1 = imin(imax(y0 + 1, ry0), ry1);
+    d.base = ((cy0 - ry0) * pitch + (cx0 - rx0)) * JP;
+    d.dx = (cx1 - cx0) * JP;
+    d.dy = (cy1 - cy0) * pitch * JP;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d.w[c] = ((o.inside[k] >> c) & 1) ? o.w[k][c] : 0.0f;
+    return d;
+  };
+
+  for (int gz0 = s2; gz0 < e2; gz0 += kBZ) {                             // z blocks of the window
+    if (t < 12) rect[t] = INT_MIN;
+    __syncthreads();
+    float acc[kVPT][NVL][4];
+#pragma unroll
+    for (int i = 0; i < kVPT; ++i)
+#pragma unroll
+      for (int n = 0; n < NVL; ++n)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][n][c] = 0.0f;
+
+    Own cur, nxt;
+    if (CACHED) load_coords(0, gz0);
+    project(0, gz0, cur);
+    __syncthreads();
+    Rect rcur = read_rect(0);
+    issue_dma(0, rcur);
+    if (CACHED && V > 1) load_coords(1, gz0);
+    for (int v = 0; v < V; ++v) {
+      if (v + 1 < V) project(v + 1, gz0, nxt);                           // overlaps view v's DMA
+      wait_vmcnt(0);                                                     // this wave's items of view v have landed
+      __syncthreads();                                                   // view v staged for everybody; rectangle v+1 complete;
+                                                                         // tile (v+1)&1 is free (view v-1 has been sampled)
+      Rect rnxt = rcur;
+      if (v + 1 < V) {
+        rnxt = read_rect(v + 1);
+        issue_dma(v + 1, rnxt);
+        if (CACHED && v + 2 < V) load_coords(v + 2, gz0);                // consumed by the next iteration's project()
+      }
+      if (t < 4) rect[4 * (v % 3) + t] = INT_MIN;                        // slot of view v (= view v+3): all its readers passed the barrier
+      // ---- sample the thread's 8 voxels of view v (owner lane i & 3 holds the descriptor of voxel i)
+      if (rcur.any) {
+        const float* src = rcur.staged ? smem + (v & 1) * tile_sz : frame + size_t(v) * view_stride;
+        auto sample = [&](const TapL& tv, float (&a)[NVL][4]) {
+#pragma unroll
+          for (int n = 0; n < NVL; ++n) {
+            const int ch0 = 16 * n + 4 * q;
+            if (ch0 < JP) {
+              const float* p0 = src + tv.base + ch0;
+              const float4 v0 = *reinterpret_cast<const float4*>(p0);
+              const float4 v1 = *reinterpret_cast<const float4*>(p0 + tv.dx);
+              const float4 v2 = *reinterpret_cast<const float4*>(p0 + tv.dy);
+              const float4 v3 = *reinterpret_cast<const float4*>(p0 + tv.dy + tv.dx);
+              float s0_ = __fmul_rn(v0.x, tv.w[0]), s1_ = __fmul_rn(v0.y, tv.w[0]);
+              float s2_ = __fmul_rn(v0.z, tv.w[0]), s3_ = __fmul_rn(v0.w, tv.w[0]);
+              s0_ = __fmaf_rn(v1.x, tv.w[1], s0_); s1_ = __fmaf_rn(v1.y, tv.w[1], s1_);
+              s2_ = __fmaf_rn(v1.z, tv.w[1], s2_); s3_ = __fmaf_rn(v1.w, tv.w[1], s3_);
+              s0_ = __fmaf_rn(v2.x, tv.w[2], s0_); s1_ = __fmaf_rn(v2.y, tv.w[2], s1_);
+              s2_ = __fmaf_rn(v2.z, tv.w[2], s2_); s3_ = __fmaf_rn(v2.w, tv.w[2], s3_);
+              s0_ = __fmaf_rn(v3.x, tv.w[3], s0_); s1_ = __fmaf_rn(v3.y, tv.w[3], s1_);
+              s2_ = __fmaf_rn(v3.z, tv.w[3], s2_); s3_ = __fmaf_rn(v3.w, tv.w[3], s3_);
+              a[n][0] = __fadd_rn(a[n][0], s0_); a[n][1] = __fadd_rn(a[n][1], s1_);
+              a[n][2] = __fadd_rn(a[n][2], s2_); a[n][3] = __fadd_rn(a[n][3], s3_);
+            }
+          }
+        };
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+          const TapL mine = finish(cur, k, rcur);
+          { const TapL tv = quad_bcast_l<0>(mine); sample(tv, acc[4 * k + 0]); }
+          { const TapL tv = quad_bcast_l<1>(mine); sample(tv, acc[4 * k + 1]); }
+          { const TapL tv = quad_bcast_l<2>(mine); sample(tv, acc[4 * k + 2]); }
+          { const TapL tv = quad_bcast_l<3>(mine); sample(tv, acc[4 * k + 3]); }
+        }
+      }
+      cur = nxt;
+      rcur = rnxt;
+    }
+    // ---- mean over views, clamp, block maxima through LDS (tile 0 is free: every sampler passes the barrier
+    //      below), then into the global planes
+    __syncthreads();
+    int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JP]
+    int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][kBZ][JP]
+    int* cyz = cxz + kBX * kBZ * JP;                                     // [kBY][kBZ][JP]
+    const int ncell = (kBX * kBY + (kBX + kBY) * kBZ) * JP;              // <= cap_px * JP (checked by the host)
+    for (int i = t; i < ncell; i += NT) cxy[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NVL; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ch = 16 * n + 4 * q + c;
+        float mz = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kVPT; ++i) {
+          const float val = clampf(__fdiv_rn(acc[i][n][c], nv), 0.0f, 1.0f);
+          mz = fmaxf(mz, val);
+          if (val > 0.0f && ch < JP) {
+            const int z = zs + 4 * i;
+            atomicMax(&cxz[(xx * kBZ + z) * JP + ch], __float_as_int(val));
+            atomicMax(&cyz[(yy * kBZ + z) * JP + ch], __float_as_int(val));
+          }
+        }
+        // the four zs lanes of a column sit 4 lanes apart inside one DPP row: rotate by 4 and 8
+        int mi = __float_as_int(mz);                                     // non-negative floats order like ints
+        mi = imax(mi, dpp_i<0x124>(mi));
+        mi = imax(mi, dpp_i<0x128>(mi));
+        if (zs == 0 && mi > 0 && ch < JP) cxy[(xx * kBY + yy) * JP + ch] = mi;
+      }
+    __syncthreads();
+    const int lz0 = gz0 - tl2;
+    for (int i = t; i < kBX * kBY * J; i += NT) {                        // xy: cell (x, y) of channel ch
+      const int ch = i / (kBX * kBY), col = i - ch * (kBX * kBY), cx = col / kBY, cy = col - cx * kBY;
+      const int vv = cxy[col * JP + ch];
+      if (vv > 0 && gx0 + cx < e0 && gy0 + cy < e1)
+        atomicMax(reinterpret_cast<int*>(&pxy[size_t(ch) * CC + (gx0 + cx - tl0) * C + (gy0 + cy - tl1)]), vv);
+    }
+    for (int i = t; i < (kBX + kBY) * kBZ * J; i += NT) {                // xz then yz rows: z fastest
+      const int ch = i / ((kBX + kBY) * kBZ), r = i - ch * ((kBX + kBY) * kBZ), a = r / kBZ, z = r - a * kBZ;
+      if (gz0 + z < e2) {
+        const int vv = cxz[r * JP + ch];                                 // rows kBX.. continue into cyz
+        if (vv > 0) {
+          if (a < kBX) {
+            if (gx0 + a < e0) atomicMax(reinterpret_cast<int*>(&pxz[size_t(ch) * CC + (gx0 + a - tl0) * C + lz0 + z]), vv);
+          } else if (gy0 + a - kBX < e1) {
+            atomicMax(reinterpret_cast<int*>(&pyz[size_t(ch) * CC + (gy0 + a - kBX - tl1) * C + lz0 + z]), vv);
+          }
+        }
+      }
+    }
+    __syncthreads();                                                     // the tiles are reused by the next z block
+  }
+}
+
+}  // namespace fvp

@@ -67,6 +67,13 @@ class HotPath:
         # fine[3], cube[3]: HOST array, passed to fvp_person_boxes by value (it becomes kernel arguments)
         self.fine_cube = (C.c_int32 * 6)(*(self.fine + [int(v) for v in cube]))
         self.fine_dev = torch.tensor(self.fine, dtype=torch.int32, device=dev)
+        self.fine_host = (C.c_int32 * 3)(*self.fine)
+        # per-sequence cache of the fine grid's sampling coordinates (what the reference caches in
+        # project_individual.py:82-94; 164 MB for the Panoptic shape set): the fused tri-plane kernel then loads
+        # 8 bytes per (voxel, view) instead of recomputing the projection.  Off above ~2 GB per camera set.
+        self.cache_fine_grid = not self._injected     # (the CPU emulation of the kernels builds it too slowly for every test)
+        self.fine_grid_limit_bytes = 2 << 30
+        self._fine_grid = None
         self.fine_axes = axes(cs.SPACE_SIZE, cs.SPACE_CENTER, self.fine)
         # center_grid [3, C*C, 2] (project_individual.py:37-40): xy at z0, xz at y0, yz at x0
         ia = axes(ins.SPACE_SIZE, cs.SPACE_CENTER, ins.VOXELS_PER_AXIS)
@@ -165,6 +172,27 @@ class HotPath:
 
     def cams_of(self, seq):
         return self._cams[self._seq_ids[seq]]
+
+    def fine_grid_cache(self, resize_transform, V):
+        """[nsets, V, F0*F1*F2, 2] sampling coordinates of the fine grid for every uploaded camera set (built by
+        fvp_sample_grid, extended when a new sequence appears), or None when a set would exceed the limit."""
+        n = self.fine[0] * self.fine[1] * self.fine[2]
+        if V * n * 8 > self.fine_grid_limit_bytes:
+            return None
+        nsets = self._cams.shape[0]
+        have = 0 if self._fine_grid is None else self._fine_grid.shape[0]
+        if have < nsets:
+            g = self.geom(resize_transform)
+            g.V = V
+            new = torch.empty((nsets, V, n, 2), device=self.device)
+            if have:
+                new[:have] = self._fine_grid
+            fa = self.fine_axes
+            for i in range(have, nsets):
+                self._call("fvp_sample_grid", _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), self.fine[0], self.fine[1],
+                           self.fine[2], _ptr(self._cams[i]), C.byref(g), _ptr(new[i]), self.stream())
+            self._fine_grid = new
+        return self._fine_grid
 
     # ---- staging ---------------------------------------------------------------------------------------
     def heat_cl(self, heatmaps, g, reuse=False):
@@ -369,9 +397,10 @@ class HotPath:
         fa = self.fine_axes
         planes = self.scratch("planes", (nP, 3, J, Cn, Cn), zero=True)
         if fused:
+            fgrid = self.fine_grid_cache(resize_transform, V) if self.cache_fine_grid else None
             self._call("fvp_project_individual_triplane", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),
-                       _ptr(boxes), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), _ptr(self.fine_dev), Cn, nP, C.byref(g),
-                       _ptr(planes), N, s)
+                       _ptr(boxes), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), self.fine_host, Cn, nP, C.byref(g),
+                       _ptr(planes), N, _ptr(fgrid), s)
         else:
             cubes = self.scratch("person_cubes", (nP, J, Cn, Cn, Cn))
             self._call("fvp_project_individual", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),

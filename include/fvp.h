@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FVP_ABI_VERSION 2
+#define FVP_ABI_VERSION 3
 #define FVP_MAX_VIEWS 8
 #define FVP_CAM_FLOATS 24 /* R[9] T[3] fx fy cx cy k[3] p[2] + 3 pad */
 #define FVP_MAX_JOINTS 32
@@ -114,12 +114,17 @@ int fvp_triplane_max(const float* cubes, float* planes, int nP, int J, int C, fv
  * (max is order-independent).  planes must be zero-filled by the caller beforehand
  * (hipMemsetAsync); cross-workgroup maxima use integer atomicMax on the non-negative floats.
  * persons_per_frame > 0 promises person_frame[p] == p / persons_per_frame (placement hint: the
- * workgroups of one frame are numbered onto one XCD); pass 0 if unknown. */
+ * workgroups of one frame are numbered onto one XCD); pass 0 if unknown.
+ * The heatmap footprint of every 8 x 4 x 32 voxel block is staged in LDS (LDS-DMA) and sampled from there.
+ * fine_grid (may be NULL): the per-sequence cache of sampling coordinates the reference keeps
+ * (project_individual.py:82-94), [nsets][V][fine0*fine1*fine2][2] as written by fvp_sample_grid on the fine
+ * axes; when given, `fine` must point to the three fine-grid sizes in HOST memory and the kernel loads the
+ * 8-byte coordinate of a (voxel, view) instead of recomputing the projection (same bits either way). */
 int fvp_project_individual_triplane(const float* heat_cl, const float* cams, const int32_t* frame_set,
                                     const int32_t* person_frame, const uint8_t* person_valid,
                                     const int32_t* boxes, const float* fx, const float* fy, const float* fz,
                                     const int32_t* fine, int C, int nP, const FvpGeom* g, float* planes,
-                                    int persons_per_frame, fvp_stream_t s);
+                                    int persons_per_frame, const float* fine_grid, fvp_stream_t s);
 
 /* ---- a-4/a-5/a-9/a-16: conv stacks ----------------------------------------------------------
  * A stack is a list of FvpConvOp over numbered activation buffers (all NCHW fp32,

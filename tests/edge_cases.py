@@ -42,7 +42,7 @@ def zero_batch_through_every_export(lib, dev):
         "fvp_project_individual": lambda: L.fvp_project_individual(p, p, ip, ip, None, ip, p, p, p, ip, Cn, 0, C.byref(g), p, s),
         "fvp_triplane_max": lambda: L.fvp_triplane_max(p, p, 0, J, Cn, s),
         "fvp_project_individual_triplane": lambda: L.fvp_project_individual_triplane(p, p, ip, ip, None, ip, p, p, p, ip, Cn, 0,
-                                                                                    C.byref(g), p, N, s),
+                                                                                    C.byref(g), p, N, None, s),
         "fvp_nms_topk": lambda: L.fvp_nms_topk(p, 0, X, Y, N, p, ip, ip, s),
         "fvp_gather_proposals": lambda: L.fvp_gather_proposals(p, p, ip, 0, J, X, Y, Z, N, p, p, p, s),
         "fvp_proposals": lambda: L.fvp_proposals(p, p, ip, p, p, 0.1, 0, N, Z, ip, p, s),

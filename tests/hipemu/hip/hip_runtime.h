@@ -205,14 +205,23 @@ static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
-// DPP quad_perm only (dpp_ctrl < 0x100): lane l reads lane (l & ~3) | sel[l & 3]
+// DPP: quad_perm (dpp_ctrl < 0x100): lane l reads lane (l & ~3) | sel[l & 3]; row_ror:n (0x121..0x12f): lane l
+// reads lane (l - n) mod 16 of its row; row_mirror (0x140) / row_half_mirror (0x141): reversed 16 / 8 lanes
 static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
   (void)old;
   const int l = hipemu::cur->lane;
-  const int sel = (ctrl >> (2 * (l & 3))) & 3;
-  return hipemu_shfl_from(src, (l & ~3) | sel);
+  int from;
+  if (ctrl < 0x100) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+  else if (ctrl >= 0x121 && ctrl <= 0x12f) from = (l & ~15) | ((l - (ctrl - 0x120)) & 15);
+  else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+  else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+  else { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+  return hipemu_shfl_from(src, from);
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
+// the value is wave-uniform wherever the kernels use it
+static inline int hipemu_readfirstlane(int v) { return v; }
+#define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
 // ---- scalar intrinsics -------------------------------------------------------------------
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }

@@ -180,6 +180,19 @@ def test_backbone_emulated_matches_bf16_oracle(emu_lib):
     assert torch.equal(cl[..., :J], y.reshape(1, J, -1).permute(0, 2, 1)) and not cl[..., J:].any()
 
 
+def test_cached_fine_grid_gives_identical_planes(emu_lib):
+    """The fused tri-plane kernel with the per-sequence coordinate cache (fine_grid) == recomputed projection."""
+    case = "tiny_g_b2_all"
+    model, cfg, cams, seq, rt, heat, meta = build_model(case, emu_lib)
+    with torch.no_grad():
+        f1, p1, c1, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        planes1 = model.engine.last_jln["planes"].clone()
+        model.engine.cache_fine_grid = True
+        f2, p2, c2, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+    assert model.engine._fine_grid is not None
+    assert torch.equal(model.engine.last_jln["planes"], planes1) and torch.equal(f1, f2) and torch.equal(p1, p2)
+
+
 # ---- edge cases shared with the GPU suite (tests/edge_cases.py) ------------------------------------
 import edge_cases as E  # noqa: E402
 
