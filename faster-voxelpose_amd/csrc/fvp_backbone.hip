@@ -40,12 +40,8 @@ __device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even
 __device__ __forceinline__ float bf2f(uint16_t h) { return __int_as_float(int(uint32_t(h) << 16)); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const Bf8& a, const Bf8& b, f32x16 c) {
-#if defined(__AMDGCN__)
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-#else
-  return hipemu_mfma_32x32x16_bf16(a.w, b.w, c);
-#endif
 }
 
 struct BbConvArgs {

@@ -62,13 +62,13 @@ struct ConvArgs {
   int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
   int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
   unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
-  int tpp, tpr_log2;  // Winograd: 2x2 tiles per plane band of a workgroup, log2(tiles per row)
+  int tpp, tpr;       // Winograd: 2x2 tiles per plane band of a workgroup, tiles per row
   int wino_ni;        // Winograd: input DMA rounds (of 512 x 16 B) per chunk
   int nunits, ysplit; // Winograd: work units (plane group x row band x cout block), cout blocks
   unsigned m_ys, m_ty; // fdiv magics: ysplit, tiles_y
   float* pool_dst;    // Winograd: if set, max_pool(2,2) of the output is written here too (one value per 2x2 tile)
   int wrow;           // k_conv_dma: floats per packed weight row (coutp, or 2*coutp for the paired transposed conv)
-  unsigned m_tpp;
+  unsigned m_tpp, m_tpr;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -813,29 +813,39 @@ static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
 static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
+static const int kWinoGeneric = int(env_size("FVP_WINO_GENERIC", 0));
 static const int kWinoWC1 = int(env_size("FVP_WINO_WC1", 0));        // diagnostics: 32-cout blocks for every layer
-// two independent 4-wave workgroups per CU (32 couts x 64 tiles each, <= 80 KB of LDS) instead of one 8-wave
-// workgroup: one workgroup's prologue / epilogue / barrier stalls overlap the other's MFMAs
+// 4-wave workgroups (32 couts x 64 tiles, <= 78 KB of LDS, two per CU) instead of one 8-wave workgroup per CU:
+// half-size work units.  Slower per FLOP when the launch has plenty of units (more LDS-DMA traffic per MFMA), but
+// a small batch (B = 1: 30 planes) has only 60-120 full-size units for 256 CUs.  FVP_WINO_HALF: 0 = automatic
+// (half-size units when the full-size ones cannot fill the CUs), 1 = always, 2 = never.  Both tilings perform the
+// same arithmetic in the same order, so the result does not depend on the choice (i.e. on the batch).
 static const int kWinoHalf = int(env_size("FVP_WINO_HALF", 0));
 static const int kWinoNoResW = int(env_size("FVP_WINO_NO_RESW", 0)); // diagnostics: stream the weights of the 32-channel layers too
 
 // Shapes the Winograd kernel covers: 3x3, even H, W a power of two in [8, 64*4] with W/2 dividing
 // a wave's 32 tiles or vice versa.  Decided from the layer SHAPE only (never from the number of
 // planes), so a frame's result does not depend on the batch it is computed in.
-static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int* TN, int* TR) {
-  if (h < 2 || (h & 1) || w < 8 || (w & (w - 1)) || (coutp != 32 && coutp % 64 != 0) || cinp % 4 != 0) return false;
-  *WC = (coutp == 32 || kWinoWC1 || kWinoHalf) ? 1 : 2;
-  *WT = (kWinoHalf ? 4 : 8) / *WC;
-  const int tpr = w / 2, TT = 16 * *WT, per_plane = (h / 2) * tpr;
-  if (TT % tpr != 0) return false;
-  if (per_plane >= TT) {
-    if (per_plane % TT != 0) return false;
+static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int* TN, int* TR, bool half = false) {
+  if (h < 2 || (h & 1) || w < 8 || (w & 3) || (coutp != 32 && coutp % 64 != 0) || cinp % 4 != 0) return false;
+  // Maps whose rows do not divide the workgroup tile (CenterNet's 80x80 / 40x40 / 20x20 levels) are supported
+  // (masked tiles) but stay on the direct kernel by default: with a handful of planes the Winograd kernel is
+  // launch-latency bound just the same (measured 582 vs 564 us for CenterNet at B = 8), and the direct form is the
+  // exact fp32 fma chain, which keeps the detection map - the input of the bit-exact top-k - closest to the
+  // reference.  FVP_WINO_GENERIC=1 enables them (a SHAPE rule either way, never the batch).
+  if ((w & (w - 1)) && !kWinoGeneric) return false;
+  *WC = (coutp == 32 || kWinoWC1 || half) ? 1 : 2;
+  *WT = (half ? 4 : 8) / *WC;
+  // a unit = TN planes x TR tile rows x (w/2) tiles <= the workgroup's 16*WT tiles; tiles beyond that product
+  // (maps whose row length does not divide the workgroup tile: 80x80, 40x40, 20x20) are masked lanes
+  const int tpr = w / 2, TT = 16 * *WT, rows = h / 2;
+  if (tpr > TT) return false;
+  if (rows * tpr >= TT) {
     *TN = 1;
     *TR = TT / tpr;
   } else {
-    if (TT % per_plane != 0) return false;
-    *TN = TT / per_plane;
-    *TR = h / 2;
+    *TN = TT / (rows * tpr);
+    *TR = rows;
   }
   return true;
 }
@@ -872,16 +882,25 @@ static int persistent_workgroups() {
 
 static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
   int WC, WT, TN, TR;
-  if (!wino_tiling(op.h, op.w, op.cinp, op.coutp, &WC, &WT, &TN, &TR)) return FVP_EINVAL;
+  if (!wino_tiling(op.h, op.w, op.cinp, op.coutp, &WC, &WT, &TN, &TR, kWinoHalf == 1)) return FVP_EINVAL;
+  if (kWinoHalf == 0) {
+    // full-size units: (rows bands) x (plane groups) x (cout blocks); switch to half-size ones when they cannot fill the CUs
+    const long units = long(ceil_div(op.h / 2, TR)) * ceil_div(planes, TN) * (op.coutp / (32 * WC));
+    int wc, wt, tn, tr;
+    if (units < persistent_workgroups() && wino_tiling(op.h, op.w, op.cinp, op.coutp, &wc, &wt, &tn, &tr, true)) {
+      WC = wc; WT = wt; TN = tn; TR = tr;
+    }
+  }
   a.wts = params + op.wino_off;
   a.TN = TN;
   a.TH = 2 * TR;
   a.TW = op.w;
   a.tiles_x = 1;
-  a.tiles_y = (op.h / 2) / TR;
+  a.tiles_y = ceil_div(op.h / 2, TR);
   a.tpp = TR * (op.w / 2);
   a.m_tpp = make_magic(a.tpp);
-  a.tpr_log2 = __builtin_ctz(unsigned(op.w / 2));
+  a.tpr = op.w / 2;
+  a.m_tpr = make_magic(a.tpr);
   a.vec = a.dma = 1;
   a.zeros = params;
   const int CBW = 32 * WC;

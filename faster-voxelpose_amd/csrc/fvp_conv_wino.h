@@ -26,10 +26,6 @@
 #ifndef FVP_WINO_IN_AUX
 #define FVP_WINO_IN_AUX 0
 #endif
-// column pass of the patch transform: 1 = packed adds (v_pk_add_f32), 0 = scalar adds
-#ifndef FVP_WINO_PK
-#define FVP_WINO_PK 1
-#endif
 
 namespace fvp {
 
@@ -38,19 +34,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Column pass of the input transform on register pairs E = (t0, t3), M = (t1, t2):
 //   v03 = (t0 - t2, t1 - t3)   v12 = (t1 + t2, t2 - t1)
-// one packed add each (the half swaps and sign flips are operand modifiers of v_pk_add_f32).
+// Plain scalar adds.  (Round 1 used two hand-written v_pk_add_f32 with op_sel / neg modifiers here.  Inline
+// asm hides the instruction from the compiler's hazard recognizer, and with one wave of the workgroup per SIMD
+// (the 4-wave tiling) under concurrent kernels the packed result was sporadically consumed by the following MFMA
+// before it was valid: timing-dependent wrong nu = 0 columns.  Scalar adds measured the same speed:
+// MI355X_MICROARCH.md lists packed f32 VALU beside MFMAs as an anti-lever anyway.)
 __device__ __forceinline__ void wino_cols(f32x2 E, f32x2 M, f32x2& v03, f32x2& v12) {
-#if defined(__AMDGCN__) && FVP_WINO_PK
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v03) : "v"(E), "v"(M));
-  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(M));
-#else
   v03 = f32x2{E.x - M.y, M.x - E.y};
   v12 = f32x2{M.x + M.y, M.y - M.x};
-#endif
 }
 
-// CC = channels per LDS chunk (4 or 8, divides cinp): the steps of a chunk are unrolled so that
-// every weight read is `chunk base + immediate`.
 // RESW: the whole Winograd-domain weight tensor of the workgroup's cout block ([cinp][CBW][16], <= 64 KB)
 // stays resident in LDS behind the three input slots (loaded once per persistent workgroup) instead of
 // streaming through the slots chunk by chunk: for the 32-channel layers the weight chunks were more than
@@ -92,10 +85,13 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   int u = next_unit(blockIdx.x);
   if (u >= nunits) return;
 
-  // this lane's 2x2 output tile inside the workgroup tile (exact cover: 16*WT = TN * tpp)
-  const int q = wt * 16 + l15;
+  // this lane's 2x2 output tile inside the workgroup tile: TN planes x TR rows x tpr tiles; lanes beyond that
+  // product (row lengths that do not divide 16*WT) compute on tile 0's data and store nothing
+  const int q0 = wt * 16 + l15;
+  const bool q_ok = q0 < a.TN * a.tpp;
+  const int q = q_ok ? q0 : 0;
   const int tn = fdiv(q, a.m_tpp), trem = q - tn * a.tpp;
-  const int ty = trem >> a.tpr_log2, tx = trem & ((1 << a.tpr_log2) - 1);
+  const int ty = fdiv(trem, a.m_tpr), tx = trem - ty * a.tpr;
   // LDS row 0 of the tile is image row y0 - 1; column 4 of a row slot is image x = 0
   const int poff = tn * plane_sz + 2 * ty * WP + 3 + 2 * tx + k4 * CS;
   const int swz = (l15 >> 2) & 3;
@@ -318,7 +314,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   const bool relu = a.flags & FVP_EPI_RELU;
   const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
   const int plane = plane0 + tn, y = y0 + 2 * ty, x = 2 * tx;
-  const bool tile_ok = plane < a.planes;
+  const bool tile_ok = q_ok && plane < a.planes && y < a.H;
   const unsigned pix = tile_ok ? unsigned(y * W + x) : 0u;
   const unsigned cbase = tile_ok ? unsigned(plane) * a.cout : 0u;
   const unsigned ppix = unsigned((y >> 1) * (W >> 1) + tx);

@@ -9,6 +9,7 @@ From one description of the topology this module derives
 Nothing here does arithmetic; BatchNorm/bias/ReLU/residual are epilogue flags of the conv
 kernel, pooling and transposed conv are ops of their own.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -61,15 +62,13 @@ class ParamTree(nn.Module):
 def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None):
     """3x3 layers the F(2x2,3x3) kernel covers (the same rule as wino_tiling() in
     csrc/fvp_conv.hip): decided from the layer shape alone, never from the batch."""
-    if (kh, kw) != (3, 3) or h < 2 or h % 2 or w < 8 or w & (w - 1) or (coutp != 32 and coutp % 64) or cinp % 4:
+    if (kh, kw) != (3, 3) or h < 2 or h % 2 or w < 8 or w % 4 or (coutp != 32 and coutp % 64) or cinp % 4:
         return False
     if cin is not None and cin != cinp:          # whole channel chunks only (no padded input channels)
         return False
-    wt = 8 if coutp == 32 else 4
-    tpr, tt, per_plane = w // 2, 16 * wt, (h // 2) * (w // 2)
-    if tt % tpr:
-        return False
-    return per_plane % tt == 0 if per_plane >= tt else tt % per_plane == 0
+    if w & (w - 1) and os.environ.get("FVP_WINO_GENERIC", "0") != "1":
+        return False                             # rows that do not divide the workgroup tile: direct kernel by default
+    return w // 2 <= (128 if coutp == 32 else 64)   # a tile row fits the workgroup's 16 * WT tiles
 
 
 class StackSpec:

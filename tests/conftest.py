@@ -20,6 +20,7 @@ def emu_lib():
     import ctypes
 
     from faster_voxelpose_amd import _capi as capi
+    os.environ.setdefault("FVP_WINO_GENERIC", "1")    # read once when the library loads: lets one test cover masked tiles
     here = os.path.join(ROOT, "tests", "hipemu")
     subprocess.run([os.path.join(here, "build_emu.sh")], check=True, capture_output=True)
     return capi.bind(ctypes.CDLL(os.path.join(here, "libfvp_emu.so")))

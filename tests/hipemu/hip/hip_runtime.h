@@ -194,6 +194,15 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(const uint32_t* a, const u
   return c;
 }
 
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 hipemu_mfma_bf16_v(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
+  uint32_t aw[4], bw[4];
+  memcpy(aw, &a, 16);
+  memcpy(bw, &b, 16);
+  return hipemu_mfma_32x32x16_bf16(aw, bw, c);
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_bf16_v
+
 // LDS-DMA: wave-uniform LDS base + lane * size, per-lane global source
 static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, __attribute__((address_space(3))) void* l,
                                unsigned size, int off, unsigned) {

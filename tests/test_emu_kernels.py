@@ -207,3 +207,22 @@ def test_negative_bbox_gives_an_empty_window(emu_lib):
 
 def test_sampling_grids_equal_reference_campus(emu_lib):
     E.sampling_grids_equal_reference(emu_lib, "cpu", "campus")
+
+
+def test_winograd_on_maps_that_do_not_divide_the_workgroup_tile(emu_lib, monkeypatch):
+    """CenterNet on a 20 x 12 detection grid with FVP_WINO_GENERIC=1: 6 tiles per row do not divide the workgroup's
+    128 tiles (masked lanes, two planes per unit) -- against the oracle's plain fp32 conv stack.  (The library reads
+    the switch once at load time: the session's emulated library is loaded by conftest with it set.)"""
+    monkeypatch.setenv("FVP_WINO_GENERIC", "1")
+    cfg = S.make_cfg("tiny", device="cpu", voxels=[20, 12, 8])
+    model = FV.FasterVoxelPoseNet(cfg, _lib=emu_lib)
+    sd = S.fill_state_dict(model.state_dict(), seed=5)
+    model.load_state_dict(sd)
+    assert any(o.wino_off > 0 for o in model.engine.specs["center_net"].op_array), "fixture must exercise the Winograd path"
+    rng = np.random.default_rng(2)
+    cubes = torch.from_numpy(rng.random((3, cfg.DATASET.NUM_JOINTS, 20, 12, 8), dtype=np.float32))
+    hm_w, sz_w = O.center_net(sd, "pose_net.center_net", cubes)
+    with torch.no_grad():
+        hm, sz = model.pose_net.center_net(cubes)
+    np.testing.assert_allclose(hm.numpy(), hm_w.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(sz.numpy(), sz_w.numpy(), rtol=2e-5, atol=2e-5)

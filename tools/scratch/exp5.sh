@@ -9,7 +9,7 @@ from faster_voxelpose_amd.models import faster_voxelpose as FV
 dev="cuda:0"
 cfg = S.make_cfg("panoptic", device=dev, min_score=-1.0)
 cams, seq = S.load_cameras("panoptic"); rt = S.resize_transform(cfg).to(dev)
-B=8
+B=int(os.environ.get("B","8"))
 heat = S.heatmaps_blobs(cfg, cams, seq, B, people=4, seed=100).to(dev)
 meta={"seq":[seq]*B}
 model = FV.get(cfg).to(dev); model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
