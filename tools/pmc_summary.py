@@ -50,11 +50,17 @@ for n in rows:
         grp[g][2] += nl
     if "k_project_triplane" in n and nl:
         out["project_triplane_bytes_per_launch"] = (2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024
+    if "k_project_whole" in n and nl:
+        out["project_whole_bytes_per_launch"] = (2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024
 for g, (f, w, n) in grp.items():
     if n:
         out[g + "_bytes_per_launch"] = (2 * f + w) * 1024 / n
         out[g + "_launches_sampled"] = n
 out["note"] = "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)"
+import datetime
+out["collected"] = datetime.date.today().isoformat()
+out["commit"] = sys.argv[3] if len(sys.argv) > 3 else "?"
+out["how"] = "tools/gpu_profile_all.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 3 --streams 1"
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     print("wrote", sys.argv[2])
