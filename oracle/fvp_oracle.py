@@ -480,7 +480,10 @@ class Oracle:
             seq = meta["seq"][i]
             cams = self._cams(cameras, seq)
             if seq not in self._fine_grids:              # cached per sequence, like the reference (:104-106)
-                self._fine_grids[seq] = fine_sample_grid(self.spec, cfg, cams, resize_transform)
+                npts = int(self.spec.fine[0]) * int(self.spec.fine[1]) * int(self.spec.fine[2])
+                # (jln128's 509 x 509 x 128 fine grid takes minutes through the emulated fma: windows are
+                #  recomputed there instead - identical arithmetic per point)
+                self._fine_grids[seq] = fine_sample_grid(self.spec, cfg, cams, resize_transform) if npts <= 12_000_000 else None
             cubes, offset, boxes = project_individual(self.spec, cfg, heatmaps[i], centers[i, mask[i]],
                                                       cams, resize_transform, self._fine_grids[seq])
             tri = triplane_max(cubes)
