@@ -8,8 +8,13 @@
 // L data | zero tail (slotw >= L + 8, <= 32); the MFMA pixel lane j is slot column j, so a tap
 // reads column j + k - pad and the halo is the zero margin.  Epilogues write whole slots (zeros
 // outside the data columns), which lets buffers share LDS space by live range.
-// Wave w owns cout block w (32 couts); accumulation order per output is the k-ordered chain
-// (channel pairs, then taps) of the generic kernel, so both paths give identical results.
+// Wave (cb, ks) owns cout block cb (32 couts) and every kKS-th channel pair of a weight chunk (split K: the
+// dependent MFMA chain of an output is 1/kKS as long, 4 * kKS waves work instead of <= 4); at the end of an
+// op the kKS partial tiles are added in the fixed order ks = 0, 1, ... through the just-consumed ring slot.
+// Measured (80 columns): 270 us with one wave per cout block, 238 us with kKS = 4; a deeper ring of smaller
+// slots (kNB = 4 x 24 KB, kKS = 2) is slower (269 us): the cost is per chunk (~3 us: scalar descriptor loads,
+// 16-wave rendezvous), not DMA latency.
+// Deterministic; differs from the generic interpreter's single k-ordered chain only in rounding.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -22,6 +27,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMaxOps = 32, kMaxBufs = 40, kMaxChunks = 112;
 constexpr int kWFloats = 12288;                       // floats per weight buffer (LDS-DMA ring)
 constexpr int kNB = 2;                               // ring depth: chunk c+1 streams in while chunk c computes
+constexpr int kKS = 4;                               // K split across waves
+constexpr int kNT1 = 256 * kKS;                      // threads per workgroup (4 cout blocks x kKS)
 
 // One pipeline step of the fused stack: `nrows` weight rows (row = (ci, tap), coutp floats each) of
 // op `op` starting at row0, or a weight-less step (pool / slot clearing) when nrows == 0.
@@ -44,14 +51,14 @@ struct Fused1dArgs {
 
 template <int KW>
 __device__ __forceinline__ void conv_chunk(const Fused1dArgs& a, const FvpConvOp& op, const Chunk& ch,
-                                           const float* lds, const float* wbuf, f32x16& acc, int lane, int cb) {
+                                           const float* lds, const float* wbuf, f32x16& acc, int lane, int cb, int ks) {
   const int half = lane >> 5, l31 = lane & 31;
   constexpr int pad = (KW - 1) / 2;
   const int sw = a.buf_w[op.src];
   const float* in = lds + a.buf_off[op.src] + l31 - pad + (2 * (ch.row0 / (2 * KW)) + half) * sw;
   const float* ws = wbuf + cb * 32 + l31 + half * KW * op.coutp;
   const int np = ch.nrows / (2 * KW);
-  for (int p = 0; p < np; ++p) {
+  for (int p = ks; p < np; p += kKS) {
 #pragma unroll
     for (int t = 0; t < KW; ++t) {
       const float av = ws[(2 * p * KW + t) * op.coutp];
@@ -61,9 +68,10 @@ __device__ __forceinline__ void conv_chunk(const Fused1dArgs& a, const FvpConvOp
   }
 }
 
-__global__ void __launch_bounds__(256) k_conv1d_fused(Fused1dArgs a) {
+__global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
   HIP_DYNAMIC_SHARED(float, lds)
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wave = wv & 3, ks = wv >> 2;             // cout block, K slice
   const int l31 = lane & 31, half = lane >> 5;
   const int plane = blockIdx.x;
   float* const wbufs = lds + a.lds_floats;           // two weight buffers behind the activation arena
@@ -78,7 +86,7 @@ __global__ void __launch_bounds__(256) k_conv1d_fused(Fused1dArgs a) {
     float* dst = wbufs + (c % kNB) * kWFloats;
     const int nq = ch.nrows * op.coutp / 4;
     int n = 0;
-    for (int g = wave; g * 64 < nq; g += 4) {
+    for (int g = wv; g * 64 < nq; g += 4 * kKS) {
       const int it = g * 64 + lane;
       ++n;
       if (it < nq)
@@ -94,13 +102,13 @@ __global__ void __launch_bounds__(256) k_conv1d_fused(Fused1dArgs a) {
 #pragma unroll
   for (int k = 0; k < kNB - 1; ++k) ninfl[k] = stage(1 + k);
   // the arena starts zeroed: channel-padding rows and out-of-slot halo reads must hit finite values
-  for (int i = t; i < a.lds_floats; i += 256) lds[i] = 0.0f;
+  for (int i = t; i < a.lds_floats; i += kNT1) lds[i] = 0.0f;
   __syncthreads();
   {                                                  // input -> buffer 0 (whole slots: zero margins)
     const int sw = a.buf_w[0];
     float* b0 = lds + a.buf_off[0];
     const float* src = a.in + size_t(plane) * a.cin * a.L;
-    for (int i = t; i < a.cin * sw; i += 256) {
+    for (int i = t; i < a.cin * sw; i += kNT1) {
       const int c = i / sw, j = i - c * sw;
       b0[i] = (j >= 4 && j < 4 + a.L) ? src[c * a.L + (j - 4)] : 0.0f;
     }
@@ -134,7 +142,7 @@ __global__ void __launch_bounds__(256) k_conv1d_fused(Fused1dArgs a) {
         const int sw = a.buf_w[op.src], dw = a.buf_w[op.dst], Lo = Lin / 2;
         const float* s = lds + a.buf_off[op.src];
         float* d = lds + a.buf_off[op.dst];
-        for (int i = t; i < op.cin * dw; i += 256) {
+        for (int i = t; i < op.cin * dw; i += kNT1) {
           const int cc = i / dw, j = i - cc * dw;
           float v = 0.0f;
           if (j >= 4 && j < 4 + Lo) v = fmaxf(s[cc * sw + 4 + 2 * (j - 4)], s[cc * sw + 4 + 2 * (j - 4) + 1]);
@@ -143,23 +151,40 @@ __global__ void __launch_bounds__(256) k_conv1d_fused(Fused1dArgs a) {
       } else {                                       // transposed conv: clear the slots before the scatter
         float* d = lds + a.buf_off[op.dst];
         const int n = op.cout * a.buf_w[op.dst];
-        for (int i = t; i < n; i += 256) d[i] = 0.0f;
+        for (int i = t; i < n; i += kNT1) d[i] = 0.0f;
       }
       rendezvous();
       continue;
     }
     const bool tr = op.kind == FVP_OP_CONVT2;
     const int ncb = op.coutp / 32;
-    if (wave < ncb) {
+    const bool active = wave < ncb;
+    float* const wcur = wbufs + (c % kNB) * kWFloats;
+    if (active) {
       if (ch.first) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
       }
-      const float* wbuf = wbufs + (c % kNB) * kWFloats;
-      if (tr || op.kw == 1) conv_chunk<1>(a, op, ch, lds, wbuf, acc, lane, wave);
-      else if (op.kw == 3) conv_chunk<3>(a, op, ch, lds, wbuf, acc, lane, wave);
-      else conv_chunk<7>(a, op, ch, lds, wbuf, acc, lane, wave);
-      if (ch.last) {
+      if (tr || op.kw == 1) conv_chunk<1>(a, op, ch, lds, wcur, acc, lane, wave, ks);
+      else if (op.kw == 3) conv_chunk<3>(a, op, ch, lds, wcur, acc, lane, wave, ks);
+      else conv_chunk<7>(a, op, ch, lds, wcur, acc, lane, wave, ks);
+    }
+    if (ch.last) {
+      // ---- K-slice reduction through the ring slot this chunk just consumed (free until the next iteration's
+      //      DMA): slices 1.. write, slice 0 adds them in order.  [ks-1][cb][r][lane]
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();                    // every wave is done reading the slot's weights
+      if (active && ks > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wcur[(((ks - 1) * 4 + wave) * 16 + r) * 64 + lane] = acc[r];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      if (active && ks == 0) {
+#pragma unroll
+        for (int k2 = 1; k2 < kKS; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] += wcur[(((k2 - 1) * 4 + wave) * 16 + r) * 64 + lane];
         // ---- epilogue: slot column j = l31; data columns [4, 4 + Lin)
         const int Lo = tr ? 2 * Lin : Lin;
         const int dw = a.buf_w[op.dst];
@@ -305,6 +330,7 @@ extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const
   static LdsOptIn optin;
   if (lds_opt_in(optin, reinterpret_cast<const void*>(&k_conv1d_fused), lds > 64 * 1024 ? 160 * 1024 : 0)) return FVP_ELIMIT;
   ProfScope ps(FVP_K_CONV, as_stream(s), flops, nops, prof_level() >= 1);
-  hipLaunchKernelGGL(k_conv1d_fused, dim3(planes), dim3(256), lds, as_stream(s), a);
+  static_assert((kKS - 1) * 4 * 16 * 64 <= kWFloats, "the K-slice partials must fit one ring slot");
+  hipLaunchKernelGGL(k_conv1d_fused, dim3(planes), dim3(kNT1), lds, as_stream(s), a);
   return launch_status();
 }

@@ -126,8 +126,9 @@ def test_conv_ragged_masked_batch_and_centernet(emu_lib):
 
 
 def test_fused_c2c_equals_generic_interpreter(emu_lib):
-    """fvp_conv_stack_run_fused_1d (whole C2CNet in one kernel) == the per-op interpreter, bit for
-    bit (same accumulation order), and both match the oracle."""
+    """fvp_conv_stack_run_fused_1d (whole C2CNet in one kernel, K split over four wave groups) vs the per-op
+    interpreter (one k-ordered chain): equal up to the rounding of the four-way partial sums, and both match
+    the oracle."""
     case = "tiny_g_b2_all"
     model, cfg, cams, seq, rt, heat, meta = build_model(case, emu_lib)
     J, Z = cfg.DATASET.NUM_JOINTS, cfg.CAPTURE_SPEC.VOXELS_PER_AXIS[2]
@@ -137,8 +138,9 @@ def test_fused_c2c_equals_generic_interpreter(emu_lib):
     fused = model.pose_net.c2c_net(z)
     model.engine.fused_c2c = False
     generic = model.pose_net.c2c_net(z)
-    assert torch.equal(fused, generic)
+    np.testing.assert_allclose(fused.numpy(), generic.numpy(), rtol=3e-6, atol=3e-6)
     np.testing.assert_allclose(fused.numpy(), O.c2c_net(sd, "pose_net.c2c_net", z).numpy(), rtol=3e-6, atol=3e-6)
+    np.testing.assert_allclose(generic.numpy(), O.c2c_net(sd, "pose_net.c2c_net", z).numpy(), rtol=3e-6, atol=3e-6)
 
 
 def test_rasteriser_kernel_matches_reference_golden(emu_lib):

@@ -188,7 +188,8 @@ def test_hipgraph_replay_equals_eager():
 
 
 def test_fused_c2c_equals_generic_gpu():
-    """One-kernel C2CNet == per-op interpreter bit for bit at the Panoptic size (80 columns)."""
+    """One-kernel C2CNet (K split over four wave groups) vs the per-op interpreter at the Panoptic size (80
+    columns): equal up to the rounding of the four-way partial sums; deterministic."""
     cfg = S.make_cfg("panoptic", device=DEV)
     model, sd = build(cfg)
     z = torch.from_numpy(np.random.default_rng(12).random((80, 15, 20), dtype=np.float32)).to(DEV)
@@ -197,7 +198,8 @@ def test_fused_c2c_equals_generic_gpu():
     model.engine.fused_c2c = False
     generic = model.pose_net.c2c_net(z)
     model.engine.fused_c2c = True
-    assert torch.equal(fused, generic)
+    np.testing.assert_allclose(fused.cpu().numpy(), generic.cpu().numpy(), rtol=3e-6, atol=3e-6)
+    assert torch.equal(fused, model.pose_net.c2c_net(z))
 
 
 @pytest.mark.gpu
