@@ -12,34 +12,46 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
   return v > bv || (v == bv && i < bi);
 }
 
-// One workgroup per frame.  LDS holds the NMS-ed map; N rounds of block arg-max.
-__global__ void __launch_bounds__(256)
+// One workgroup (1024 threads) per frame.  The map is copied to LDS once (coalesced), the 3x3 NMS reads its nine
+// neighbours from there, then N rounds of block arg-max over the kept values: every thread owns <= 16 cells in
+// registers, a round is a register scan + DPP-free shuffle tree + one 16-entry LDS stage.
+constexpr int kNmsThreads = 1024, kNmsCells = 16;   // up to 128 x 128 cells per frame
+__global__ void __launch_bounds__(kNmsThreads)
 k_nms_topk(const float* __restrict__ hm, int X, int Y, int N, float* __restrict__ vals, long long* __restrict__ idx,
            long long* __restrict__ flat) {
-  HIP_DYNAMIC_SHARED(float, kept)               // [X*Y] + 8 slots for the cross-wave stage
+  HIP_DYNAMIC_SHARED(float, raw)                // [X*Y] raw map | 16 values | 16 indices
   const int b = blockIdx.x, t = threadIdx.x, n = X * Y;
   const float* m = hm + size_t(b) * n;
-  float* wv = kept + n;                         // [4] values
-  int* wi = reinterpret_cast<int*>(kept + n + 4);  // [4] indices
-  for (int i = t; i < n; i += 256) {
-    const int x = i / Y, y = i - x * Y;
-    const float c = m[i];
-    float mx = c;
-    for (int dx = -1; dx <= 1; ++dx)
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int xx = x + dx, yy = y + dy;
-        if (xx >= 0 && xx < X && yy >= 0 && yy < Y) mx = fmaxf(mx, m[xx * Y + yy]);
-      }
-    // keep = (x == max).float(); keep * x   (core/proposal.py:23-25)
-    kept[i] = __fmul_rn((c == mx) ? 1.0f : 0.0f, c);
-  }
+  float* wv = raw + n;
+  int* wi = reinterpret_cast<int*>(raw + n + 16);
+  for (int i = t; i < n; i += kNmsThreads) raw[i] = m[i];
   __syncthreads();
+  // kept value of this thread's cells i = t + 1024 c (the host limits X * Y to kNmsCells * 1024)
+  float kv[kNmsCells];
+#pragma unroll
+  for (int c = 0; c < kNmsCells; ++c) {
+    const int i = t + c * kNmsThreads;
+    kv[c] = -INFINITY;
+    if (i < n) {
+      const int x = i / Y, y = i - x * Y;
+      const float cv = raw[i];
+      float mx = cv;
+      for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int xx = x + dx, yy = y + dy;
+          if (xx >= 0 && xx < X && yy >= 0 && yy < Y) mx = fmaxf(mx, raw[xx * Y + yy]);
+        }
+      // keep = (x == max).float(); keep * x   (core/proposal.py:23-25)
+      kv[c] = __fmul_rn((cv == mx) ? 1.0f : 0.0f, cv);
+    }
+  }
   for (int k = 0; k < N; ++k) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = t; i < n; i += 256) {
-      const float v = kept[i];
-      if (better(v, i, bv, bi)) { bv = v; bi = i; }
+#pragma unroll
+    for (int c = 0; c < kNmsCells; ++c) {
+      const int i = t + c * kNmsThreads;
+      if (i < n && better(kv[c], i, bv, bi)) { bv = kv[c]; bi = i; }
     }
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o);
@@ -48,18 +60,23 @@ k_nms_topk(const float* __restrict__ hm, int X, int Y, int N, float* __restrict_
     }
     if ((t & 63) == 0) { wv[t >> 6] = bv; wi[t >> 6] = bi; }
     __syncthreads();
+    // every thread reduces the 16 wave winners (broadcast reads) so the winner is known everywhere without a second barrier
+    bv = wv[0];
+    bi = wi[0];
+    for (int w = 1; w < kNmsThreads / 64; ++w)
+      if (better(wv[w], wi[w], bv, bi)) { bv = wv[w]; bi = wi[w]; }
+    if (bi == 0x7fffffff) bi = 0;               // N > number of finite cells: degenerate, pick cell 0 (value -inf)
     if (t == 0) {
-      for (int w = 1; w < 4; ++w)
-        if (better(wv[w], wi[w], bv, bi)) { bv = wv[w]; bi = wi[w]; }
-      if (bi == 0x7fffffff) bi = 0;             // N > number of finite cells: degenerate, pick cell 0
-      vals[size_t(b) * N + k] = bi < n ? kept[bi] : 0.0f;
+      vals[size_t(b) * N + k] = bv;
       flat[size_t(b) * N + k] = bi;
       // the reference unravels with shape[1] = X for both coordinates (core/proposal.py:16-17)
       idx[(size_t(b) * N + k) * 2 + 0] = bi / X;
       idx[(size_t(b) * N + k) * 2 + 1] = bi % X;
-      if (bi < n) kept[bi] = -INFINITY;
     }
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kNmsCells; ++c)
+      if (t + c * kNmsThreads == bi) kv[c] = -INFINITY;   // the owner retires the winner
+    __syncthreads();                              // wv / wi are rewritten next round
   }
 }
 
@@ -126,13 +143,13 @@ using namespace fvp;
 extern "C" int fvp_nms_topk(const float* hm2d, int B, int X, int Y, int N, float* vals, int64_t* idx, int64_t* flat,
                             fvp_stream_t s) {
   FVP_REQUIRE(hm2d && vals && idx && flat && B >= 0 && X > 0 && Y > 0 && N > 0);
-  const size_t lds = size_t(X) * Y * 4 + 32;
-  FVP_LIMIT(lds <= 160 * 1024 && N <= X * Y);
+  const size_t lds = size_t(X) * Y * 4 + 128;
+  FVP_LIMIT(lds <= 160 * 1024 && N <= X * Y && X * Y <= kNmsCells * kNmsThreads);
   static LdsOptIn optin;
   if (lds_opt_in(optin, reinterpret_cast<const void*>(&k_nms_topk), lds > 64 * 1024 ? 160 * 1024 : 0)) return FVP_ELIMIT;
   if (B == 0) return 0;
   ProfScope ps(FVP_K_OTHER, as_stream(s));
-  hipLaunchKernelGGL(k_nms_topk, dim3(B), dim3(256), lds, as_stream(s), hm2d, X, Y, N, vals,
+  hipLaunchKernelGGL(k_nms_topk, dim3(B), dim3(kNmsThreads), lds, as_stream(s), hm2d, X, Y, N, vals,
                      reinterpret_cast<long long*>(idx), reinterpret_cast<long long*>(flat));
   return launch_status();
 }
