@@ -27,6 +27,7 @@
 #define FVP_BB_NBUF 1
 #endif
 
+
 namespace fvp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,6 +62,7 @@ struct BbConvArgs {
   int ntaps, K, relu, out_jp;
   int ncls;               // 1, or 4 parity classes of a transposed conv on blockIdx.z (tap tables / weights per class)
   signed char dy[64], dx[64];
+  int toff[32];           // k_bb_conv_dma: element offset (dy * W + dx) * Cinp of tap t (class-major for transposed convs)
 };
 
 // pixel index -> (image, row, col).  Plain integer division: the operand reaches N*OH*OW (millions), far
@@ -273,145 +275,196 @@ __global__ void __launch_bounds__(256) k_bb_conv(BbConvArgs a) {
   }
 }
 
-// Large-tile variant for layers with >= 256 couts and enough pixels: 8 waves, 256 pixels x 256 couts per
-// workgroup, 64 x 128 per wave (2 x 4 MFMA tiles = 128 accumulator registers, two waves per SIMD), so a k step
-// needs 6 ds_read_b128 for 8 MFMAs instead of 4 for 4 -- the 128 x 128 kernel is bound by LDS read bandwidth.
-// Both operand tiles are copied by the LDS-DMA (global_load_lds, 16 B per lane, no staging registers) into two
-// 72 KB slots: chunk c+1 streams in while chunk c is multiplied.  Row pitch 144 bytes = 9 DMA lanes per row, the
-// ninth reading a zero page; out-of-image taps, rows beyond M and k beyond K read the zero page as well.
-__global__ void __launch_bounds__(512, 2) k_bb_conv_big(BbConvArgs a, const uint16_t* __restrict__ zeros) {
-  constexpr int BM = 256, BN = 256, BK = 64, LP = BK + 8, QPR = 9;   // quads (16 B) per LDS row incl. the pad quad
-  constexpr int SLOT = (BM + BN) * LP;                               // bf16 elements per slot
-  constexpr int NITEM = BM * QPR;                                    // DMA items of one operand tile (2304)
-  constexpr int NR = (NITEM + 511) / 512;                            // DMA rounds per operand (5; the last one half full)
-  HIP_DYNAMIC_SHARED(uint16_t, smem)
-  signed char* tdy = reinterpret_cast<signed char*>(smem + 2 * SLOT);
-  signed char* tdx = tdy + 64;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+// Large-tile variant (every layer whose input has >= 64 stored channels and whose output is plain bf16 NHWC):
+// 8 waves, 256 pixels x BN couts per workgroup (BN = 256 / 128 / 64), 64 x BN/2 per wave, so a k step needs
+// 2 + BN/64 ds_read_b128 for BN/16 MFMAs -- the 128 x 128 kernel above needs one read per MFMA and is bound by
+// LDS read bandwidth.  Both operand tiles are copied by the LDS-DMA (global_load_lds, 16 B per lane, no staging
+// registers) into two slots: chunk c+1 streams in while chunk c is multiplied.
+//   * LDS rows are 128 bytes (one 64-wide k chunk) without padding; the 16-byte k group g of row r is stored at
+//     position g ^ ((r >> 1) & 7), which makes the MFMA operand fetches conflict-free: a ds_read_b128 is served in
+//     the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32), and within each the 8 even and the 8 odd rows
+//     must land on 8 different positions (r & 7 does not do that: rows 12 and 20 collide, measured as 48 % of the
+//     LDS cycles).  The DMA writes lane-contiguous LDS, so lane (row, position p) reads source group p ^ swz(row).
+//   * a k chunk lies inside one tap (Cinp % 64 == 0), so everything per-lane is hoisted out of the k loop: the
+//     lane's source pointers at tap (0, 0), one validity bit per tap, the weight row pointers.  Per chunk a lane
+//     adds one wave-uniform offset and selects the zero page for invalid taps: ~6 VALU instructions per 16-byte
+//     item instead of ~40 (the address arithmetic used to cost as much issue time as the MFMAs).
+//   * workgroup id -> (pixel tile, cout tile) keeps the cout tiles of one pixel tile on one XCD, back to back:
+//     the activation tile is fetched into that XCD's L2 once.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {          // v_cvt_pk_bf16_f32 (RNE)
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+template <int BN, int BK, int NSLOT>
+__global__ void __launch_bounds__(512, 2) k_bb_conv_dma(BbConvArgs a, const uint16_t* __restrict__ zeros) {
+  constexpr int BM = 256, ROWB = 2 * BK;                             // LDS row = one k chunk of a pixel / cout: 128 or 64 bytes
+  constexpr int GPR = BK / 8;                                        // 16-byte k groups per row
+  constexpr int SLOTB = (BM + BN) * ROWB;                            // bytes per slot
+  constexpr int NRA = BM * GPR / 512, NRB = BN * GPR / 512;          // DMA rounds (512 lanes x 16 B) per operand tile
+  constexpr int LPC = NRA + NRB;                                     // DMA instructions per wave and chunk
+  constexpr int D = NSLOT - 1;                                       // chunks in flight ahead of the one being multiplied
+  constexpr int WN = BN / 2, NJ = WN / 32;                           // couts / MFMA tiles per wave
+  static_assert(NRA >= 1 && NRB >= 1 && (BK == 64 || BK == 32), "tile shape");
+  HIP_DYNAMIC_SHARED(uint16_t, smem16)
+  char* smem = reinterpret_cast<char*>(smem16);
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int M = a.N * a.OH * a.OW;
-  const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
-  const int cls = blockIdx.z;                          // parity class of a transposed conv (0 otherwise)
+  // workgroup id -> XCD (id & 7) -> that XCD's pixel tiles, cout tiles innermost
+  const int nct = a.Coutp / BN, nin = nct * a.ncls;    // (class, cout tile) innermost: they share the activation tile
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int inner = seq % nin;
+  const int mt = (seq / nin) * 8 + xcd, ct = inner % nct;
+  if (mt * BM >= M) return;
+  const int m0 = mt * BM, co0 = ct * BN;
+  const int cls = inner / nct;                         // parity class of a transposed conv (0 otherwise)
   const int opy = a.ncls > 1 ? cls >> 1 : a.py, opx = a.ncls > 1 ? (cls & 1) : a.px;
   const uint16_t* wcls = a.w + size_t(cls) * a.Coutp * a.K;
-  if (t < 64) {
-    tdy[t] = a.dy[(t + cls * a.ntaps) & 63];
-    tdx[t] = a.dx[(t + cls * a.ntaps) & 63];
-  }
-  // ---- this lane's DMA items (fixed over the k loop): A item -> (pixel row, k group), B item -> (cout row, k group)
-  int a_iy0[NR], a_ix0[NR], a_base[NR], qv[NR];       // qv = k group 0..7, or -1: pad quad / item beyond the tile
-  bool a_ok[NR];                                      // pixel row inside M
-  int b_row[NR];                                      // element offset of the weight row
+  const int tap0 = cls * a.ntaps;
+  // the 16-byte k group g of row r sits at position g ^ swz(r): conflict-free operand fetches
+  auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+
+  // ---- this lane's DMA items (fixed over the k loop)
+  const uint16_t* ap[NRA];                            // source of this item's k group at tap (0, 0), channel 0
+  uint32_t amask[NRA];                                // bit t: tap t of this pixel lies inside the image
+  const uint16_t* bp[NRB];
 #pragma unroll
-  for (int j = 0; j < NR; ++j) {
+  for (int j = 0; j < NRA; ++j) {
     const int it = (wave + 8 * j) * 64 + lane;
-    const int row = it / QPR, q = it - row * QPR;
-    qv[j] = (it < NITEM && q < 8) ? q : -1;
-    a_ok[j] = false;
-    a_iy0[j] = a_ix0[j] = a_base[j] = 0;
-    b_row[j] = (co0 + (row < BN ? row : 0)) * a.K;    // packed weights are padded to Coutp rows
+    const int row = it / GPR, g = (it % GPR) ^ swz(row);
     const int am = m0 + row;
-    if (qv[j] >= 0 && am < M) {
-      int n, oy, ox;
-      bb_decode(am, a.OW, a.OH * a.OW, n, oy, ox);
-      a_iy0[j] = oy * a.stride;
-      a_ix0[j] = ox * a.stride_x;
-      a_base[j] = n * a.H * a.W;
-      a_ok[j] = true;
+    const bool ok = am < M;
+    int n, oy, ox;
+    bb_decode(ok ? am : 0, a.OW, a.OH * a.OW, n, oy, ox);
+    const int iy0 = oy * a.stride, ix0 = ox * a.stride_x;
+    ap[j] = a.in + ((size_t(n) * a.H + iy0) * a.W + ix0) * a.Cinp + g * 8;
+    uint32_t mk = 0;
+    for (int tp = 0; tp < a.ntaps; ++tp) {
+      const int iy = iy0 + a.dy[(tap0 + tp) & 63], ix = ix0 + a.dx[(tap0 + tp) & 63];
+      if (ok && unsigned(iy) < unsigned(a.H) && unsigned(ix) < unsigned(a.W)) mk |= 1u << tp;
     }
+    amask[j] = mk;
   }
-  __syncthreads();                                    // tap table visible
-  const int nchunks = (a.K + BK - 1) / BK;
-  auto stage = [&](int chunk, int slot) {
-    uint16_t* As = smem + slot * SLOT;
-    uint16_t* Bs = As + BM * LP;
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int g = wave + 8 * j;
-      if (g * 64 < NITEM) {                           // wave-uniform: the last round is issued by half of the waves
-        const int kk = chunk * BK + (qv[j] < 0 ? 0 : qv[j]) * 8;
-        const bool k_ok = qv[j] >= 0 && kk < a.K;
-        const int kc = k_ok ? kk : 0;
-        const int tap = kc >> a.cin_log2, c0 = kc & (a.Cinp - 1);
-        const int iy = a_iy0[j] + tdy[tap], ix = a_ix0[j] + tdx[tap];
-        const bool ok = a_ok[j] && k_ok && unsigned(iy) < unsigned(a.H) && unsigned(ix) < unsigned(a.W);
-        const uint16_t* src = ok ? a.in + (size_t(a_base[j] + iy * a.W + ix) * a.Cinp + c0) : zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(As + g * 512), 16, 0, 0);
-        const uint16_t* wsrc = k_ok ? wcls + size_t(b_row[j]) + kc : zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
-                                         (__attribute__((address_space(3))) void*)(Bs + g * 512), 16, 0, 0);
-      }
+  for (int j = 0; j < NRB; ++j) {
+    const int it = (wave + 8 * j) * 64 + lane;
+    const int row = it / GPR, g = (it % GPR) ^ swz(row);
+    bp[j] = wcls + size_t(co0 + row) * a.K + g * 8;   // packed weights are padded to Coutp rows
+  }
+  const int nchunks = a.K / BK;
+  // k order: channel block outermost, taps innermost -- consecutive chunks re-read the same activation rows shifted
+  // by one tap, while they are still in the XCD's L2 (tap-major order touched them again only Cinp / 64 chunks of
+  // 32 CUs x 64 KB later: beyond a 4 MB L2)
+  int st_tap = 0, st_c0 = 0;
+  auto stage = [&](int chunk) {
+    const int tap = st_tap, c0 = st_c0;
+    if (++st_tap == a.ntaps) {
+      st_tap = 0;
+      st_c0 += BK;
     }
+    const int kk = tap * a.Cinp + c0;                 // position in the packed weights [cout][tap][cin]
+    const int soff = a.toff[(tap0 + tap) & 31] + c0;  // wave-uniform element offset of (tap, c0)
+    const uint32_t bit = 1u << tap;
+    char* As = smem + (chunk % NSLOT) * SLOTB;
+    char* Bs = As + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < NRA; ++j) {
+      const uint16_t* src = (amask[j] & bit) ? ap[j] + soff : zeros;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(As + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NRB; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[j] + kk),
+                                       (__attribute__((address_space(3))) void*)(Bs + (wave + 8 * j) * 1024), 16, 0, 0);
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  stage(0, 0);
-  wait_vmcnt(0);
-  __syncthreads();
+  // operand fetch offsets: row (tile row + l31), k group 2 ks + half
+  const int a_rd = (wm * 64 + l31) * ROWB, b_rd = (BM + wn * WN + l31) * ROWB;
+  int xo[BK / 16];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) xo[ks] = ((2 * ks + half) ^ swz(l31)) << 4;
+
+  // ring of NSLOT slots, D = NSLOT - 1 chunks in flight ahead of the MFMAs.  Used with two 64-wide slots: four
+  // 32-wide slots (three chunks in flight, same LDS) measured 4-8 % slower -- twice the barriers -- so the DMA
+  // stream is not latency-starved; ablations put the k loop at MFMA 45 %, DMA issue / landing 30 %, operand
+  // fetches 15 %, barriers 10 % of the time (deconv 256->256 at 64x120)
+#pragma unroll
+  for (int c = 0; c < D; ++c)
+    if (c < nchunks) stage(c);
   for (int c = 0; c < nchunks; ++c) {
-    const int slot = c & 1;
-    if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
-    const uint16_t* As = smem + slot * SLOT;
-    const uint16_t* Bs = As + BM * LP;
+    const int ahead = nchunks - 1 - c;                // chunks issued after c (at most D - 1 before this iteration's stage)
+    wait_vmcnt((ahead < D - 1 ? ahead : D - 1) * LPC);  // this wave's share of chunk c has landed
+    __syncthreads();                                  // ... everybody's; and everybody is done reading chunk c - 1
+    if (c + D < nchunks) stage(c + D);                // into the slot of chunk c - 1
+    const char* S = smem + (c % NSLOT) * SLOTB;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      Bf8 fa[2], fb[4];
+      Bf8 fa[2], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const Bf8*>(As + (wm * 64 + i * 32 + l31) * LP + ks * 16 + 8 * half);
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const Bf8*>(S + a_rd + i * 32 * ROWB + xo[ks]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const Bf8*>(Bs + (wn * 128 + j * 32 + l31) * LP + ks * 16 + 8 * half);
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const Bf8*>(S + b_rd + j * 32 * ROWB + xo[ks]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
     }
-    wait_vmcnt(0);                                    // this wave's share of chunk c+1 has landed
-    __syncthreads();                                  // ... everybody's; and everybody is done reading chunk c
   }
+  __syncthreads();                                    // every wave is done with the slots: the epilogue reuses them
 
-  // ---- epilogue: as in k_bb_conv (bf16 NHWC output through wave-private fp32 LDS tiles, 32 couts at a time)
+  // ---- epilogue: bf16 NHWC output through wave-private fp32 LDS tiles (32 couts at a time) so that a lane
+  // ends up with 8 consecutive channels of one pixel: 16-byte residual loads and 16-byte stores
   const float* scale = a.epi;
   const float* shift = a.epi + a.Coutp;
   constexpr int EP = 32 + 4;
   float* et = reinterpret_cast<float*>(smem) + wave * (64 * EP);
+  size_t pixv[4];                                     // this lane's four (pixel row, channel group) vectors
+  bool rowok[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float sc = scale[co0 + wn * 128 + j * 32 + l31], sh = shift[co0 + wn * 128 + j * 32 + l31];
-    __builtin_amdgcn_wave_barrier();
+  for (int v = 0; v < 4; ++v) {
+    const int row = (lane + 64 * v) >> 2;
+    const int m = m0 + wm * 64 + row;
+    rowok[v] = m < M;
+    const int mm = rowok[v] ? m : 0;
+    size_t pix = size_t(mm);
+    if (a.os != 1) {
+      int n_, oy, ox;
+      bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
+      pix = (size_t(n_) * a.ROH + oy * a.os + opy) * a.ROW + ox * a.os + opx;
+    }
+    pixv[v] = pix * a.Cbuf;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cj = co0 + wn * WN + j * 32;
+    const float sc = scale[cj + l31], sh = shift[cj + l31];
+    const int co = cj + (lane & 3) * 8;
+    const bool co_ok = co < a.Cbuf;
+    Bf8 resv[4];
+    if (a.res) {                                      // unconditional, clamped residual loads first
+#pragma unroll
+      for (int v = 0; v < 4; ++v) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v] + (co_ok ? co : 0));
+    }
+    __builtin_amdgcn_wave_barrier();                  // the previous block's readers are done
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP + l31] = acc[i][j][r] * sc + sh;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // own LDS writes landed (wave-private tile)
     __builtin_amdgcn_wave_barrier();
-    size_t pixv[4];
-    bool okv[4];
-    Bf8 resv[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int idx = lane + 64 * v, row = idx >> 2, g = idx & 3;
-      const int m = m0 + wm * 64 + row;
-      const int co = co0 + wn * 128 + j * 32 + g * 8;
-      okv[v] = m < M && co < a.Cbuf;
-      const int mm = okv[v] ? m : 0;
-      size_t pix = size_t(mm);
-      if (a.os != 1) {
-        int n_, oy, ox;
-        bb_decode(mm, a.OW, a.OH * a.OW, n_, oy, ox);
-        pix = (size_t(n_) * a.ROH + oy * a.os + opy) * a.ROW + ox * a.os + opx;
-      }
-      pixv[v] = pix * a.Cbuf + (okv[v] ? co : 0);
-      if (a.res) resv[v] = *reinterpret_cast<const Bf8*>(a.res + pixv[v]);
-    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int idx = lane + 64 * v, row = idx >> 2, g = idx & 3;
@@ -430,9 +483,9 @@ __global__ void __launch_bounds__(512, 2) k_bb_conv_big(BbConvArgs a, const uint
           v0 = fmaxf(v0, 0.0f);
           v1 = fmaxf(v1, 0.0f);
         }
-        o.w[e] = uint32_t(f2bf(v0)) | (uint32_t(f2bf(v1)) << 16);
+        o.w[e] = pack_bf16x2(v0, v1);
       }
-      if (okv[v]) *reinterpret_cast<Bf8*>(a.out + pixv[v]) = o;
+      if (rowok[v] && co_ok) *reinterpret_cast<Bf8*>(a.out + pixv[v] + co) = o;
     }
   }
 }
@@ -602,19 +655,41 @@ static int bb_launch(const BbConvArgs& a, dim3 grid, hipStream_t s) {
   return launch_status();
 }
 
+template <int BN, int BK, int NSLOT>
+static int bb_launch_dma(const BbConvArgs& a, int M, hipStream_t s, const uint16_t* zeros) {
+  constexpr size_t lds_max = size_t(NSLOT) * (256 + BN) * 2 * BK, lds_ep = 8 * 64 * 36 * sizeof(float);
+  static_assert(lds_max >= lds_ep, "epilogue staging fits the ring");
+  // a short k loop touches only its first chunks' slots: less LDS = more workgroups per CU for the 1x1 expansions
+  const size_t used = size_t(std::min(NSLOT, a.K / BK)) * (256 + BN) * 2 * BK;
+  const size_t lds = std::max(used, lds_ep);
+  static LdsOptIn optin;
+  auto k = &k_bb_conv_dma<BN, BK, NSLOT>;
+  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds_max)) return e;
+  const int nmt = ceil_div(M, 256), nct = a.Coutp / BN;
+  hipLaunchKernelGGL(k, dim3(unsigned(8 * ceil_div(nmt, 8) * nct * a.ncls)), dim3(512), lds, s, a, zeros);
+  return launch_status();
+}
+
 static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const uint16_t* zeros) {
   const int M = a.N * a.OH * a.OW;
   static const bool no_big = getenv("FVP_BB_NO_BIG") != nullptr;
-  static const long big_min = getenv("FVP_BB_BIG_MIN_TILES") ? atol(getenv("FVP_BB_BIG_MIN_TILES")) : 100;   // (tests: 1)
-  // large tiles whenever the layer has >= 256 couts (measured faster than the 128 x 128 kernel down to ~150
-  // workgroups: 685 vs 455 TFLOP/s on the 512->512 3x3 at 16x30) and the output is plain bf16 NHWC
-  if (!no_big && op.coutp % 256 == 0 && long(ceil_div(M, 256)) * (op.coutp / 256) * a.ncls >= big_min && a.out && !a.out_cl &&
-      !a.out_nchw && (a.Cbuf & 7) == 0 && size_t(op.coutp) * a.K < (1u << 30)) {
-    constexpr size_t lds = 2 * (256 + 256) * 72 * sizeof(uint16_t) + 128;
-    static LdsOptIn optin;
-    if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(&k_bb_conv_big), lds)) return e;
-    hipLaunchKernelGGL(k_bb_conv_big, dim3(ceil_div(M, 256), op.coutp / 256, a.ncls), dim3(512), lds, s, a, zeros);
-    return launch_status();
+  static const int bn_cap = getenv("FVP_BB_DMA_BN") ? atoi(getenv("FVP_BB_DMA_BN")) : 256;     // diagnostics
+  // LDS-DMA kernel: a k chunk of 64 inside one tap, plain bf16 NHWC output, offsets within 32 bits
+  if (!no_big && op.cinp % 64 == 0 && op.coutp % 128 == 0 && a.ntaps * a.ncls <= 32 && a.out && !a.out_cl && !a.out_nchw && (a.Cbuf & 7) == 0 &&
+      size_t(op.coutp) * a.K < (1u << 30) && size_t(a.N) * a.H * a.W * a.Cinp < (1u << 30)) {
+    for (int i = 0; i < a.ntaps * a.ncls; ++i) a.toff[i] = (int(a.dy[i]) * a.W + int(a.dx[i])) * a.Cinp;
+    // 256 couts per workgroup unless that leaves the chip badly filled: W workgroups run in ceil(W / 256) rounds, a
+    // 128-wide tile needs ~1.2x the time per output but halves the granule (3x3 256->256 at 32x60: 300 workgroups =
+    // two rounds, the second one 17 % full); the single-chunk expansions with a residual are HBM-bound and gain from
+    // two resident workgroups per CU (less LDS, 112 registers)
+    int bn = 128;
+    if (op.coutp % 256 == 0 && bn_cap >= 256) {
+      const long W = long(ceil_div(M, 256)) * (op.coutp / 256) * a.ncls;
+      const double r256 = double(ceil_div(W, 256L)), r128 = double(ceil_div(2 * W, 256L)) * 0.5 * 1.2;
+      const bool small_k = a.K == 64 && a.res;
+      if (!(r128 < r256 || small_k)) bn = 256;
+    }
+    return bn == 256 ? bb_launch_dma<256, 64, 2>(a, M, s, zeros) : bb_launch_dma<128, 64, 2>(a, M, s, zeros);
   }
   const bool wide = op.coutp % 128 == 0;
   dim3 grid(ceil_div(M, 128), op.coutp / (wide ? 128 : 64), a.ncls);

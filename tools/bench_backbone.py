@@ -12,6 +12,10 @@ import torch  # noqa: E402
 import fvp_synthetic as S  # noqa: E402
 from faster_voxelpose_amd.core import config as CFG  # noqa: E402
 from faster_voxelpose_amd.models import resnet as RN  # noqa: E402
+from faster_voxelpose_amd import _capi as _capi0  # noqa: E402
+
+if os.environ.get("FVP_LIB"):          # diagnostics only: a variant built by tools/build_variant.sh
+    _capi0.LIB_PATH = os.path.abspath(os.environ["FVP_LIB"])
 
 
 def per_op(m, x, a):
