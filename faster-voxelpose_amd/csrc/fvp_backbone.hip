@@ -672,8 +672,10 @@ static int bb_launch_dma(const BbConvArgs& a, int M, hipStream_t s, const uint16
 
 static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const uint16_t* zeros) {
   const int M = a.N * a.OH * a.OW;
-  static const bool no_big = getenv("FVP_BB_NO_BIG") != nullptr;
-  static const int bn_cap = getenv("FVP_BB_DMA_BN") ? atoi(getenv("FVP_BB_DMA_BN")) : 256;     // diagnostics
+  // diagnostics / tests (read per launch so that a test can switch them): the register-staged kernel only, or
+  // 128-cout tiles only
+  const bool no_big = getenv("FVP_BB_NO_BIG") != nullptr;
+  const int bn_cap = getenv("FVP_BB_DMA_BN") ? atoi(getenv("FVP_BB_DMA_BN")) : 256;
   // LDS-DMA kernel: a k chunk of 64 inside one tap, plain bf16 NHWC output, offsets within 32 bits
   if (!no_big && op.cinp % 64 == 0 && op.coutp % 128 == 0 && a.ntaps * a.ncls <= 32 && a.out && !a.out_cl && !a.out_nchw && (a.Cbuf & 7) == 0 &&
       size_t(op.coutp) * a.K < (1u << 30) && size_t(a.N) * a.H * a.W * a.Cinp < (1u << 30)) {

@@ -425,6 +425,29 @@ def test_backbone_full_image_size_vs_oracle():
         assert float((y[n] - o32[n]).norm() / o32[n].norm()) < 1.5 * e_orc + 2e-3
 
 
+@pytest.mark.gpu
+def test_backbone_tile_shapes_give_identical_heatmaps(monkeypatch):
+    """The LDS-DMA conv kernel with 256-cout tiles where they fill the chip (default), with 128-cout tiles everywhere
+    and at a batch that leaves partial pixel tiles / partial XCD groups: the tile shape changes neither the k order
+    nor the MFMA shape, so the heatmaps are bit-identical.  The register-staged 128 x 128 kernel walks k tap-major
+    instead: equal up to bf16 rounding flips."""
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    cfg = CFG.default_config()
+    m = RN.get(cfg).to("cuda:0")
+    m.load_state_dict(S.fill_backbone_state_dict(m.state_dict(), seed=5))
+    x = torch.from_numpy(np.random.default_rng(2).random((3, 3, 160, 224), dtype=np.float32)).cuda()
+    with torch.no_grad():
+        y0 = m(x).clone()
+        monkeypatch.setenv("FVP_BB_DMA_BN", "128")
+        y1 = m(x).clone()
+        monkeypatch.delenv("FVP_BB_DMA_BN")
+        monkeypatch.setenv("FVP_BB_NO_BIG", "1")
+        y2 = m(x).clone()
+    assert torch.equal(y0, y1)
+    assert float((y2 - y0).norm() / y0.norm()) < 2e-2 and not torch.equal(y2, torch.zeros_like(y2))
+
+
 # ---- edge cases shared with the emulator suite (tests/edge_cases.py) ---------------------------------
 @pytest.mark.gpu
 def test_zero_batch_through_every_export():
