@@ -164,8 +164,12 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    # FVP_BENCH_FORCE_DIST=1: initialise RCCL and run the result gather for a single rank too (a one-GPU check of
+    # the N > 1 code path: process group, communication stream, all_gather_into_tensor)
+    force_dist = world == 1 and os.environ.get("FVP_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import fvp_synthetic as S
@@ -210,7 +214,7 @@ def main():
 
     # the gather of batch t runs on its own stream behind batch t's completion event, so it never fences
     # the compute pipeline (core/distributed.py)
-    gatherer = D.ResultGatherer(world, device=dev)
+    gatherer = D.ResultGatherer(world, device=dev, always=force_dist)
 
     def step(i=0, pipelined=True):
         if bb is not None:
@@ -227,18 +231,27 @@ def main():
         ev.record()
         return gatherer.gather(fused, ev)
 
+    if world > 1 or force_dist:
+        # RCCL builds its communicator lazily inside the first collective (seconds of host time with an idle GPU);
+        # do that before the warm-up steps so that they, not the communicator set-up, precede the timed region
+        gatherer.gather(torch.zeros(B, 1, device=dev))
+        gatherer.synchronize()
+        dist.barrier()
     with torch.no_grad():
         for i in range(max(args.warmup, nstreams if args.warmup else 0)):
             out = step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             out = step(i)
+        t_sub = time.perf_counter()
         torch.cuda.synchronize()                 # every stream of the device: compute pipeline and gathers
-        if world > 1:
+        if os.environ.get("FVP_BENCH_DEBUG"):
+            print(f"[debug] submit {1e3 * (t_sub - t0):.2f} ms, drain {1e3 * (time.perf_counter() - t_sub):.2f} ms", file=sys.stderr)
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -261,7 +274,7 @@ def main():
             torch.cuda.synchronize()
     lib.fvp_prof_enable(0)
     prof_steps = max(1, args.prof_steps)
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -359,7 +372,7 @@ def main():
             "mpjpe_vs_ref_mm": mpjpe, "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

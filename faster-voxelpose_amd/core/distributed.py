@@ -37,17 +37,18 @@ class ResultGatherer:
 
     ``stream`` / ``stream_ctx`` are injectable so the ordering contract can be tested without a GPU."""
 
-    def __init__(self, world, device=None, stream=None, stream_ctx=None):
+    def __init__(self, world, device=None, stream=None, stream_ctx=None, always=False):
         self.world = int(world)
+        self.always = bool(always)      # run the collective for world == 1 too (single-GPU check of the RCCL path)
         self.device = torch.device(device) if device is not None else None
         on_gpu = self.device is not None and self.device.type == "cuda"
         if stream is not None:
             self.stream = stream
-        elif on_gpu and self.world > 1:
+        elif on_gpu and (self.world > 1 or self.always):
             self.stream = torch.cuda.Stream(device=self.device)
         else:
             self.stream = _InlineStream()
-        self._ctx = stream_ctx if stream_ctx is not None else (torch.cuda.stream if on_gpu and self.world > 1 else None)
+        self._ctx = stream_ctx if stream_ctx is not None else (torch.cuda.stream if on_gpu and (self.world > 1 or self.always) else None)
         self._out = {}
         self._slot = 0
 
@@ -63,7 +64,7 @@ class ResultGatherer:
         return buf
 
     def gather(self, local, ready=None):
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return local
         if ready is not None:
             self.stream.wait_event(ready)               # the ONLY dependency: batch t -> gather t
