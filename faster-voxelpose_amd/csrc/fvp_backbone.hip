@@ -63,6 +63,10 @@ struct BbConvArgs {
   int ncls;               // 1, or 4 parity classes of a transposed conv on blockIdx.z (tap tables / weights per class)
   signed char dy[64], dx[64];
   int toff[32];           // k_bb_conv_dma: element offset (dy * W + dx) * Cinp of tap t (class-major for transposed convs)
+  // k_bb_conv_dma<.., FUSE>: the 1x1 heatmap layer applied to this layer's output tile (which is then not stored)
+  const uint16_t* w2;     // [Coutp2 >= 32][K2] packed weights of the heatmap layer, K2 = this layer's Coutp
+  const float* epi2;      // its scale | shift, each Coutp2
+  int K2, Cout2, Coutp2;
 };
 
 // pixel index -> (image, row, col).  Plain integer division: the operand reaches N*OH*OW (millions), far
@@ -298,7 +302,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {          /
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
-template <int BN, int BK, int NSLOT>
+template <int BN, int BK, int NSLOT, bool FUSE = false>
 __global__ void __launch_bounds__(512, 2) k_bb_conv_dma(BbConvArgs a, const uint16_t* __restrict__ zeros) {
   constexpr int BM = 256, ROWB = 2 * BK;                             // LDS row = one k chunk of a pixel / cout: 128 or 64 bytes
   constexpr int GPR = BK / 8;                                        // 16-byte k groups per row
@@ -431,6 +435,88 @@ __global__ void __launch_bounds__(512, 2) k_bb_conv_dma(BbConvArgs a, const uint
   const float* shift = a.epi + a.Coutp;
   constexpr int EP = 32 + 4;
   float* et = reinterpret_cast<float*>(smem) + wave * (64 * EP);
+  if constexpr (FUSE) {
+    // ---- fused heatmap layer (final_layer, resnet.py:199): heat[pixel][joint] = sum_c bf16(relu(bn(acc)))[pixel][c] *
+    // W2[joint][c] over the workgroup's 256 channels (one cout tile: co0 = 0).  The staged 64 x 32 block is read back
+    // in the MFMA A layout (row l31, 8 channels per half), rounded to bf16 exactly as the stored activation would be,
+    // and multiplied with W2 (B operand: joint l31); the two cout halves (wn) are summed through LDS.
+    f32x16 hacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hacc[i][r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int cj = wn * WN + j * 32;
+      const float sc = scale[cj + l31], sh = shift[cj + l31];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) et[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP + l31] = acc[i][j][r] * sc + sh;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const Bf8 fb = *reinterpret_cast<const Bf8*>(a.w2 + size_t(l31) * a.K2 + cj + 16 * ks + 8 * half);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float* src = et + (i * 32 + l31) * EP + 16 * ks + 8 * half;
+          const float4 lo = *reinterpret_cast<const float4*>(src);
+          const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+          float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          Bf8 fa;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v0 = x[2 * e], v1 = x[2 * e + 1];
+            if (a.relu) {
+              v0 = fmaxf(v0, 0.0f);
+              v1 = fmaxf(v1, 0.0f);
+            }
+            fa.w[e] = pack_bf16x2(v0, v1);
+          }
+          hacc[i] = mfma_bf16(fa, fb, hacc[i]);
+        }
+      }
+    }
+    float* red = reinterpret_cast<float*>(smem + 8 * 64 * EP * sizeof(float)) + wm * (64 * 32);   // behind the staging tiles
+    if (wn == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = hacc[i][r];
+    }
+    __syncthreads();
+    if (wn == 1) return;
+    const float sc2 = a.epi2[l31], sh2 = a.epi2[a.Coutp2 + l31];
+    const size_t hw = size_t(a.ROH) * a.ROW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                    // four consecutive pixel rows per register quad
+        const int rb = i * 32 + 8 * q + 4 * half;
+        int n_, oy, ox;
+        const int mb = m0 + wm * 64 + rb;
+        bb_decode(mb < M ? mb : 0, a.OW, a.OH * a.OW, n_, oy, ox);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (mb + e < M) {
+            const size_t pix = (size_t(n_) * a.ROH + oy * a.os + opy) * a.ROW + ox * a.os + opx;
+            const float v = (hacc[i][4 * q + e] + red[(rb + e) * 32 + l31]) * sc2 + sh2;
+            if (a.out_cl && l31 < a.out_jp) a.out_cl[pix * a.out_jp + l31] = l31 < a.Cout2 ? v : 0.0f;
+            if (a.out_nchw && l31 < a.Cout2) a.out_nchw[(size_t(n_) * a.Cout2 + l31) * hw + (pix - size_t(n_) * hw)] = v;
+          }
+          if (++ox == a.OW) {                          // next pixel of the GEMM row walk
+            ox = 0;
+            if (++oy == a.OH) {
+              oy = 0;
+              ++n_;
+            }
+          }
+        }
+      }
+    return;
+  }
   size_t pixv[4];                                     // this lane's four (pixel row, channel group) vectors
   bool rowok[4];
 #pragma unroll
@@ -655,15 +741,16 @@ static int bb_launch(const BbConvArgs& a, dim3 grid, hipStream_t s) {
   return launch_status();
 }
 
-template <int BN, int BK, int NSLOT>
+template <int BN, int BK, int NSLOT, bool FUSE = false>
 static int bb_launch_dma(const BbConvArgs& a, int M, hipStream_t s, const uint16_t* zeros) {
-  constexpr size_t lds_max = size_t(NSLOT) * (256 + BN) * 2 * BK, lds_ep = 8 * 64 * 36 * sizeof(float);
+  constexpr size_t lds_max = size_t(NSLOT) * (256 + BN) * 2 * BK;
+  constexpr size_t lds_ep = 8 * 64 * 36 * sizeof(float) + (FUSE ? 4 * 64 * 32 * sizeof(float) : 0);   // staging (+ wn reduction)
   static_assert(lds_max >= lds_ep, "epilogue staging fits the ring");
   // a short k loop touches only its first chunks' slots: less LDS = more workgroups per CU for the 1x1 expansions
   const size_t used = size_t(std::min(NSLOT, a.K / BK)) * (256 + BN) * 2 * BK;
   const size_t lds = std::max(used, lds_ep);
   static LdsOptIn optin;
-  auto k = &k_bb_conv_dma<BN, BK, NSLOT>;
+  auto k = &k_bb_conv_dma<BN, BK, NSLOT, FUSE>;
   if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds_max)) return e;
   const int nmt = ceil_div(M, 256), nct = a.Coutp / BN;
   hipLaunchKernelGGL(k, dim3(unsigned(8 * ceil_div(nmt, 8) * nct * a.ncls)), dim3(512), lds, s, a, zeros);
@@ -677,6 +764,10 @@ static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const 
   const bool no_big = getenv("FVP_BB_NO_BIG") != nullptr;
   const int bn_cap = getenv("FVP_BB_DMA_BN") ? atoi(getenv("FVP_BB_DMA_BN")) : 256;
   // LDS-DMA kernel: a k chunk of 64 inside one tap, plain bf16 NHWC output, offsets within 32 bits
+  if (a.w2) {                                          // heatmap layer fused into this layer (eligibility: fvp_bb_run)
+    for (int i = 0; i < a.ntaps * a.ncls; ++i) a.toff[i] = (int(a.dy[i]) * a.W + int(a.dx[i])) * a.Cinp;
+    return bb_launch_dma<256, 64, 2, true>(a, M, s, zeros);
+  }
   if (!no_big && op.cinp % 64 == 0 && op.coutp % 128 == 0 && a.ntaps * a.ncls <= 32 && a.out && !a.out_cl && !a.out_nchw && (a.Cbuf & 7) == 0 &&
       size_t(op.coutp) * a.K < (1u << 30) && size_t(a.N) * a.H * a.W * a.Cinp < (1u << 30)) {
     for (int i = 0; i < a.ntaps * a.ncls; ++i) a.toff[i] = (int(a.dy[i]) * a.W + int(a.dx[i])) * a.Cinp;
@@ -742,6 +833,26 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       a.out_jp = heat_jp;
       a.out_nchw = heat_nchw;
     }
+    // the 1x1 heatmap layer behind a 256-cout layer is applied in that layer's epilogue: its 256-channel output
+    // (the largest activation of the network) is never written or read
+    bool fused_heat = false;
+    if (i + 1 < nops && !getenv("FVP_BB_NO_FUSE_FINAL") && !getenv("FVP_BB_NO_BIG")) {
+      const FvpBbOp& nx = ops[i + 1];
+      if (nx.kind == FVP_BB_CONV && (nx.flags & FVP_BB_OUT_HEAT) && nx.src == op.dst && nx.res < 0 && nx.kh == 1 && nx.kw == 1 &&
+          nx.stride == 1 && nx.pad == 0 && nx.cinp == 256 && op.coutp == 256 && op.cout == 256 && op.cinp % 64 == 0 && op.res < 0 &&
+          nx.cout <= 32 && nx.coutp >= 32 && (op.kind == FVP_BB_DECONV || op.kh * op.kw <= 9) &&
+          size_t(N) * op.h * op.w * op.cinp < (1u << 30) && ((heat_cl && heat_jp >= nx.cout && heat_jp <= 32) || (!heat_cl && heat_nchw))) {
+        fused_heat = true;
+        a.w2 = wblob + nx.w_off;
+        a.epi2 = eblob + nx.e_off;
+        a.K2 = nx.cinp;
+        a.Cout2 = nx.cout;
+        a.Coutp2 = nx.coutp;
+        a.out_cl = heat_cl;
+        a.out_jp = heat_jp;
+        a.out_nchw = heat_nchw;
+      }
+    }
     if (op.kind == FVP_BB_CONV) {
       FVP_LIMIT(op.kh * op.kw <= 64);
       a.OH = op.oh;
@@ -766,6 +877,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       a.ncls = 1;
       a.w = wblob + op.w_off;
       if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
+      if (fused_heat) ++i;
     } else {
       // ConvTranspose(k4, s2, p1): output (2y + py, 2x + px) gathers input rows y + dy: py = 0 -> (ky 1, dy 0),
       // (ky 3, dy -1); py = 1 -> (ky 0, dy +1), (ky 2, dy 0)
@@ -786,6 +898,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       }
       a.w = wblob + op.w_off;
       if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
+      if (fused_heat) ++i;
     }
   }
   return 0;
