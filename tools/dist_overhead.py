@@ -1,3 +1,6 @@
+"""Cost of the multi-GPU result gather on ONE GPU (diagnostics): RCCL process group of world size 1, three batches in
+flight, the gather of every batch on its own stream (core/distributed.py) against no gather / a plain copy.
+   gpurun -- python tools/dist_overhead.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, torch.distributed as dist

@@ -1,3 +1,4 @@
+# PMC passes (SQ, LDS, TCC) over the backbone conv kernels:  gpurun -- bash tools/gpu_pmc_backbone.sh
 cd /tmp; export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/pmc_bb; rm -rf $out; mkdir -p $out
 cmd="python $root/tools/bench_backbone.py --images 40 --iters 2"

@@ -1,3 +1,4 @@
+# PMC passes over the projection kernels:  gpurun -- bash tools/gpu_pmc_projection.sh
 cd /tmp; export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/pmc_tri; mkdir -p $out
 cat > /tmp/run_tri.py <<'PY'
@@ -17,7 +18,7 @@ with torch.no_grad():
     for _ in range(3): out = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
 torch.cuda.synchronize()
 PY
-run() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -o p -- python $root/tools/scratch/run_step.py > $out/$name.log 2>&1; echo "$name rc=$?"; }
+run() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -o p -- python $root/tools/run_step.py > $out/$name.log 2>&1; echo "$name rc=$?"; }
 run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES
 run sq2 SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC
 python - <<'PY'

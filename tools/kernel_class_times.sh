@@ -1,3 +1,4 @@
+# Per-class kernel time of one serial B=8 step through the fvp_prof_* hooks (FVP_LIB=<variant .so> to compare builds).
 python - <<'PY'
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.getcwd())

@@ -1,5 +1,6 @@
+"""Three serial forward passes of the B = 8 Panoptic-shape step (target of the rocprofv3 wrappers in tools/)."""
 import sys, os
-ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import fvp_synthetic as S
