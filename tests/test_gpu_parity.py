@@ -442,9 +442,16 @@ def test_backbone_tile_shapes_give_identical_heatmaps(monkeypatch):
         monkeypatch.setenv("FVP_BB_DMA_BN", "128")
         y1 = m(x).clone()
         monkeypatch.delenv("FVP_BB_DMA_BN")
+        monkeypatch.setenv("FVP_BB_NO_FUSE_FINAL", "1")      # heatmap layer as its own kernel
+        y3 = m(x).clone()
+        cl3 = m.forward_channels_last(x).clone()
+        monkeypatch.delenv("FVP_BB_NO_FUSE_FINAL")
+        cl0 = m.forward_channels_last(x).clone()
         monkeypatch.setenv("FVP_BB_NO_BIG", "1")
         y2 = m(x).clone()
     assert torch.equal(y0, y1)
+    # fused heatmap layer: the same bf16 products, summed per cout half and then across -> fp32 rounding only
+    assert torch.allclose(y0, y3, rtol=1e-4, atol=2e-6) and torch.allclose(cl0, cl3, rtol=1e-4, atol=2e-6)
     assert float((y2 - y0).norm() / y0.norm()) < 2e-2 and not torch.equal(y2, torch.zeros_like(y2))
 
 
