@@ -69,6 +69,12 @@ struct ConvArgs {
   float* pool_dst;    // Winograd: if set, max_pool(2,2) of the output is written here too (one value per 2x2 tile)
   int wrow;           // k_conv_dma: floats per packed weight row (coutp, or 2*coutp for the paired transposed conv)
   unsigned m_tpp, m_tpr;
+  // paired transposed conv with 32 couts: the 1x1 conv that consumes its output (P2PNet's output layer,
+  // cnns_2d.py:142) applied in the epilogue; the 32-channel map itself is then not stored
+  const float* w2;    // packed [32][coutp2 = 32] weights of that conv
+  const float* epi2;  // its bias | scale | shift
+  float* dst2;        // its output [planes][cout2][OH][OW]
+  int cout2, flags2;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -353,10 +359,11 @@ __device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x16 (&a
 }
 
 // Epilogue of the paired transposed conv: blocks cb / cb + CB/2 are output columns 2x / 2x+1.
-template <int CB, int PB, bool HAS_RES>
+template <int CB, int PB, bool HAS_RES, bool FUSE2 = false>
 __device__ __forceinline__ void conv_epilogue_tpair(const ConvArgs& a, f32x16 (&acc)[CB][PB], int wave, int l31,
-                                                    int half, int plane0, int y0, int dy) {
+                                                    int half, int plane0, int y0, int dy, const float* w2s = nullptr) {
   constexpr int CH = CB / 2;
+  static_assert(!FUSE2 || CH == 1, "the fused 1x1 conv needs all 32 couts of a pixel in one lane pair");
   const float* bias = a.epi;
   const float* scale = a.epi + a.coutp;
   const float* shift = a.epi + 2 * a.coutp;
@@ -399,7 +406,48 @@ __device__ __forceinline__ void conv_epilogue_tpair(const ConvArgs& a, f32x16 (&
           if (HAS_RES && res_after) x += rr[e];
           v[e] = x;
         }
-        if (ok[r]) *reinterpret_cast<float2*>(a.dst + o[r]) = make_float2(v[0], v[1]);
+        if (FUSE2) {
+          acc[cb][pb][r] = v[0];                     // keep the finished values in the accumulator registers
+          acc[cb + CH][pb][r] = v[1];
+        } else if (ok[r]) {
+          *reinterpret_cast<float2*>(a.dst + o[r]) = make_float2(v[0], v[1]);
+        }
+      }
+    }
+    if (FUSE2) {
+      // out[j] = sum_co W2[co][j] * y[co] for this lane's two pixels: a lane holds 16 of the 32 channels (rows
+      // (r&3) + 8(r>>2) + 4 half), its partner lane ^ 32 the other 16; W2 sits in LDS as [co][32]
+      const float* bias2 = a.epi2;
+      const float* scale2 = a.epi2 + 32;
+      const float* shift2 = a.epi2 + 64;
+      const bool relu2 = a.flags2 & FVP_EPI_RELU;
+      const unsigned pb2 = pix_ok ? unsigned(plane) * a.cout2 : 0u;
+#pragma unroll
+      for (int j0 = 0; j0 < 16; j0 += 4) {
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float4 w = *reinterpret_cast<const float4*>(w2s + co * 32 + j0);
+          const float y0v = acc[0][pb][r], y1v = acc[CH][pb][r];
+          s0[0] = fmaf(w.x, y0v, s0[0]);  s1[0] = fmaf(w.x, y1v, s1[0]);
+          s0[1] = fmaf(w.y, y0v, s0[1]);  s1[1] = fmaf(w.y, y1v, s1[1]);
+          s0[2] = fmaf(w.z, y0v, s0[2]);  s1[2] = fmaf(w.z, y1v, s1[2]);
+          s0[3] = fmaf(w.w, y0v, s0[3]);  s1[3] = fmaf(w.w, y1v, s1[3]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = j0 + jj;
+          const float t0 = s0[jj] + __shfl_xor(s0[jj], 32), t1 = s1[jj] + __shfl_xor(s1[jj], 32);
+          if ((jj & 1) == half && pix_ok && j < a.cout2) {         // the two lanes of a pair share the stores
+            float x0 = bn_affine(t0, bias2[j], scale2[j], shift2[j]), x1 = bn_affine(t1, bias2[j], scale2[j], shift2[j]);
+            if (relu2) {
+              x0 = fmaxf(x0, 0.0f);
+              x1 = fmaxf(x1, 0.0f);
+            }
+            *reinterpret_cast<float2*>(a.dst2 + (pb2 + j) * unsigned(OHW) + pix) = make_float2(x0, x1);
+          }
+        }
       }
     }
   }
@@ -658,6 +706,19 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
     else
       conv_epilogue_pair<PB, false>(a, acc[0], wave, l31, half, plane0, y0);
   } else if (TPAIR) {
+    if constexpr (CB == 2) {
+      if (a.w2) {                                      // fused 1x1 output conv: its weights [32][32] through LDS
+        float* w2s = smem + 4;                         // (the chunk loop ended with a barrier: the slots are free)
+        for (int i = threadIdx.x; i < 32 * 32 / 4; i += 256)
+          reinterpret_cast<float4*>(w2s)[i] = reinterpret_cast<const float4*>(a.w2)[i];
+        __syncthreads();
+        if (a.flags & FVP_EPI_RES)
+          conv_epilogue_tpair<CB, PB, true, true>(a, acc, wave, l31, half, plane0, y0, tapT, w2s);
+        else
+          conv_epilogue_tpair<CB, PB, false, true>(a, acc, wave, l31, half, plane0, y0, tapT, w2s);
+        return;
+      }
+    }
     if (a.flags & FVP_EPI_RES)
       conv_epilogue_tpair<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, tapT);
     else
@@ -812,6 +873,7 @@ static const int kNoDma = int(env_size("FVP_CONV_NO_DMA", 0));
 static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
 static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
+static const int kNoHeadFuse = int(env_size("FVP_CONV_NO_HEAD_FUSE", 0));
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
 static const int kWinoGeneric = int(env_size("FVP_WINO_GENERIC", 0));
 static const int kWinoWC1 = int(env_size("FVP_WINO_WC1", 0));        // diagnostics: 32-cout blocks for every layer
@@ -992,9 +1054,17 @@ static int plan_and_launch_tpair(const FvpConvOp& op, ConvArgs a, const float* p
 // Tile selection: all couts per workgroup (CB = coutp/32), PB so that CB*PB <= 8 accumulator
 // tiles per wave, the tile shaped to cover full image rows where possible.
 static int plan_and_launch(const FvpConvOp& op, const float* params, float* const* bufs, int planes,
-                           const uint8_t* plane_valid, int valid_div, hipStream_t s, float* pool_dst = nullptr) {
+                           const uint8_t* plane_valid, int valid_div, hipStream_t s, float* pool_dst = nullptr,
+                           const FvpConvOp* head = nullptr) {
   ConvArgs a{};
   a.pool_dst = pool_dst;
+  if (head) {                                          // (eligibility checked by the caller)
+    a.w2 = params + head->w_off;
+    a.epi2 = params + head->e_off;
+    a.dst2 = bufs[head->dst];
+    a.cout2 = head->cout;
+    a.flags2 = head->flags;
+  }
   const bool tr = op.kind == FVP_OP_CONVT2;
   const int kh = tr ? 1 : op.kh, kw = tr ? 1 : op.kw;
   a.src = bufs[op.src];
@@ -1154,7 +1224,20 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
             break;
           }
       }
-      rc = plan_and_launch(op, params, bufs, planes, plane_valid, valid_div, as_stream(s), pool_dst);
+      // a 32-cout paired transposed conv whose only consumer is the next op, a plain 1x1 conv (P2PNet's output
+      // layer): that conv runs in the transposed conv's epilogue and the 32-channel map is never stored
+      const FvpConvOp* head = nullptr;
+      if (op.kind == FVP_OP_CONVT2 && op.h > 1 && op.pair_off > 0 && !kNoPair && !kNoHeadFuse && op.w % 4 == 0 && op.coutp == 32 &&
+          i + 1 < nops) {
+        const FvpConvOp& nx = ops[i + 1];
+        bool only = nx.kind == FVP_OP_CONV && nx.kh == 1 && nx.kw == 1 && nx.src == op.dst && nx.res < 0 && nx.cin == op.cout &&
+                    nx.cinp == 32 && nx.coutp == 32 && nx.cout <= 16 && nx.h == 2 * op.h && nx.w == 2 * op.w && nx.dst != op.dst &&
+                    nx.dst >= 0 && nx.dst < nbufs;
+        for (int j = i + 2; j < nops && only; ++j) only = ops[j].src != op.dst && ops[j].res != op.dst;
+        if (only) head = &nx;
+      }
+      rc = plan_and_launch(op, params, bufs, planes, plane_valid, valid_div, as_stream(s), pool_dst, head);
+      if (!rc && head) ++i;
     } else {
       rc = FVP_EINVAL;
     }
