@@ -8,8 +8,9 @@ from faster_voxelpose_amd import _capi as capi
 if os.environ.get("FVP_LIB"): capi.LIB_PATH = os.path.abspath(os.environ["FVP_LIB"])
 from faster_voxelpose_amd.models import faster_voxelpose as FV
 dev="cuda:0"
-cfg = S.make_cfg("panoptic", device=dev, min_score=-1.0)
-cams, seq = S.load_cameras("panoptic"); rt = S.resize_transform(cfg).to(dev)
+CFGN = os.environ.get("CFG", "panoptic")
+cfg = S.make_cfg(CFGN, device=dev, min_score=-1.0)
+cams, seq = S.load_cameras(CFGN); rt = S.resize_transform(cfg).to(dev)
 B=int(os.environ.get("B","8"))
 heat = S.heatmaps_blobs(cfg, cams, seq, B, people=4, seed=100).to(dev)
 meta={"seq":[seq]*B}
