@@ -309,12 +309,9 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
 
 // Epilogue of the PAIR layout: accumulator rows co / 16+co of a lane are pixels 2j / 2j+1 of the
 // same cout -> one float2 store per cout, 256 contiguous bytes per 32 lanes.
-// FUSE2: a 1x1 conv that reads this layer's output (the first res-block's skip conv, cnns_2d.py:29-32) is applied
-// to the finished values as well: a lane pair (l, l ^ 32) holds all 16 channels of two pixels.  This layer's own
-// output is still stored (the res branch reads it).
-template <int PB, bool HAS_RES, bool FUSE2 = false>
+template <int PB, bool HAS_RES>
 __device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x16 (&acc)[PB], int wave, int l31, int half,
-                                                   int plane0, int y0, const float* w2s = nullptr) {
+                                                   int plane0, int y0) {
   const float* bias = a.epi;
   const float* scale = a.epi + a.coutp;
   const float* shift = a.epi + 2 * a.coutp;
@@ -357,44 +354,6 @@ __device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x16 (&a
         v[e] = x;
       }
       if (ok[r]) *reinterpret_cast<float2*>(a.dst + o[r]) = make_float2(v[0], v[1]);
-      if (FUSE2) {
-        acc[pb][r] = v[0];
-        acc[pb][r + 8] = v[1];
-      }
-    }
-    if (FUSE2) {
-      const float* bias2 = a.epi2;
-      const float* scale2 = a.epi2 + 32;
-      const float* shift2 = a.epi2 + 64;
-      const bool relu2 = a.flags2 & FVP_EPI_RELU;
-      const unsigned pb2 = pix_ok ? unsigned(plane) * a.cout2 : 0u;
-#pragma unroll
-      for (int j0 = 0; j0 < 32; j0 += 4) {
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int co = (r & 3) + 8 * (r >> 2) + 4 * half;             // this lane's 8 of the 16 channels
-          const float4 w = *reinterpret_cast<const float4*>(w2s + co * 32 + j0);
-          const float y0v = acc[pb][r], y1v = acc[pb][r + 8];
-          s0[0] = fmaf(w.x, y0v, s0[0]);  s1[0] = fmaf(w.x, y1v, s1[0]);
-          s0[1] = fmaf(w.y, y0v, s0[1]);  s1[1] = fmaf(w.y, y1v, s1[1]);
-          s0[2] = fmaf(w.z, y0v, s0[2]);  s1[2] = fmaf(w.z, y1v, s1[2]);
-          s0[3] = fmaf(w.w, y0v, s0[3]);  s1[3] = fmaf(w.w, y1v, s1[3]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = j0 + jj;
-          const float t0 = s0[jj] + __shfl_xor(s0[jj], 32), t1 = s1[jj] + __shfl_xor(s1[jj], 32);
-          if ((jj & 1) == half && pix_ok && j < a.cout2) {
-            float x0 = bn_affine(t0, bias2[j], scale2[j], shift2[j]), x1 = bn_affine(t1, bias2[j], scale2[j], shift2[j]);
-            if (relu2) {
-              x0 = fmaxf(x0, 0.0f);
-              x1 = fmaxf(x1, 0.0f);
-            }
-            *reinterpret_cast<float2*>(a.dst2 + (pb2 + j) * unsigned(HW) + pix) = make_float2(x0, x1);
-          }
-        }
-      }
     }
   }
 }
@@ -742,17 +701,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
   }
   if (a.ablate & 8) return;
   if (PAIR) {
-    if (a.w2) {                                        // fused 1x1 consumer: its weights [16][32] through LDS
-      float* w2s = smem + 4;
-      for (int i = threadIdx.x; i < 16 * 32 / 4; i += 256)
-        reinterpret_cast<float4*>(w2s)[i] = reinterpret_cast<const float4*>(a.w2)[i];
-      __syncthreads();
-      if (a.flags & FVP_EPI_RES)
-        conv_epilogue_pair<PB, true, true>(a, acc[0], wave, l31, half, plane0, y0, w2s);
-      else
-        conv_epilogue_pair<PB, false, true>(a, acc[0], wave, l31, half, plane0, y0, w2s);
-      return;
-    }
     if (a.flags & FVP_EPI_RES)
       conv_epilogue_pair<PB, true>(a, acc[0], wave, l31, half, plane0, y0);
     else
@@ -1252,13 +1200,11 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
   // a 2x2 max-pool that reads the output of a Winograd conv is produced by that conv's epilogue
   // (one pooled value per 2x2 output tile): the pool launch and its re-read of the map disappear
   unsigned long long pooled = 0;                       // bit j: pool op j already done
-  unsigned long long fused_ops = 0;                    // bit j: conv op j already computed in its producer's epilogue
   for (int i = 0; i < nops; ++i) {
     const FvpConvOp& op = ops[i];
     FVP_REQUIRE(op.src >= 0 && op.src < nbufs && op.dst >= 0 && op.dst < nbufs && op.res < nbufs);
     int rc;
     if (op.kind == FVP_OP_POOL2 && i < 64 && ((pooled >> i) & 1)) continue;
-    if (i < 64 && ((fused_ops >> i) & 1)) continue;
     if (op.kind == FVP_OP_POOL2) {
       FVP_REQUIRE(op.w % 2 == 0 && (op.h == 1 || op.h % 2 == 0));
       const long total = long(planes) * op.cin * (op.h > 1 ? op.h / 2 : 1) * (op.w / 2);
@@ -1289,27 +1235,6 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
                     nx.dst >= 0 && nx.dst < nbufs;
         for (int j = i + 2; j < nops && only; ++j) only = ops[j].src != op.dst && ops[j].res != op.dst;
         if (only) head = &nx;
-      }
-      // a pixel-pair 7x7 conv (16 couts): a 1x1 conv among the next ops that reads its output (the first res-block's
-      // skip conv) is computed in its epilogue as a second output
-      if (!head && op.kind == FVP_OP_CONV && op.pair_off > 0 && !kNoPair && !kNoHeadFuse && op.w % 4 == 0 && op.coutp == 32 &&
-          op.cout == 16 && op.kh == 7 && op.kw == 7) {
-        for (int j = i + 1; j < nops && j < i + 4 && j < 64; ++j) {
-          const FvpConvOp& nx = ops[j];
-          if (nx.kind == FVP_OP_CONV && nx.kh == 1 && nx.kw == 1 && nx.src == op.dst && nx.res < 0 && nx.cin == 16 && nx.cinp == 16 &&
-              nx.coutp == 32 && nx.h == op.h && nx.w == op.w && nx.dst != op.dst && nx.dst != op.src && nx.dst >= 0 && nx.dst < nbufs) {
-            bool clean = true;                         // nobody in between writes the fused conv's output buffer or reads it
-            for (int m = i + 1; m < j; ++m) clean = clean && ops[m].dst != nx.dst && ops[m].src != nx.dst && ops[m].res != nx.dst;
-            if (clean) {
-              head = &nx;
-              fused_ops |= 1ull << j;
-            }
-            break;
-          }
-        }
-        rc = plan_and_launch(op, params, bufs, planes, plane_valid, valid_div, as_stream(s), pool_dst, head);
-        if (rc) return rc;
-        continue;
       }
       rc = plan_and_launch(op, params, bufs, planes, plane_valid, valid_div, as_stream(s), pool_dst, head);
       if (!rc && head) ++i;
