@@ -735,7 +735,7 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
     const int nbx = ceil_div(C, kBX), nby = ceil_div(C, kBY);
     // two tiles per workgroup, two workgroups (512 threads, <= 128 VGPRs) per CU: 4 x 36 KB + state
     const int cap_px = int((36 * 1024) / (size_t(g->JP) * 4));
-    FVP_LIMIT(cap_px >= kBX * kBY + (kBX + kBY) * kBZ);
+    FVP_LIMIT(cap_px >= kBX * kBY + (kBX + kBY) * (nvl == 1 ? 32 : 16));      // the block's plane cells alias tile 0
     const size_t lds = 2 * size_t(cap_px) * g->JP * 4 + 64;
     const int F0 = fine_grid ? fine[0] : 0, F1 = fine_grid ? fine[1] : 0, F2 = fine_grid ? fine[2] : 0;
 #define CALL(NVL_, CACHED_)                                                                                        \

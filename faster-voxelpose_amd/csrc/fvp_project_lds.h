@@ -72,24 +72,23 @@ __device__ __forceinline__ int row_max(int v) {
   return v;
 }
 
-#ifndef FVP_TRI_BZ
-#define FVP_TRI_BZ 32
-#endif
-constexpr int kBX = 8, kBY = 4, kBZ = FVP_TRI_BZ;   // voxel block of a workgroup
-constexpr int kVPT = kBZ / 4;                  // voxels per thread: z = zs + 4 i
-constexpr int kOwn = kVPT / 4;                 // voxels a lane projects per view (i = q + 4 k)
+constexpr int kBX = 8, kBY = 4;                 // voxel block of a workgroup in x, y; in z: 32 (one channel quad per
+                                               // lane) or 16 (two: J = 17), so that both forms stay within 128 VGPRs
 constexpr int kTriThreads = kBX * kBY * 4 * 4; // (x, y, zs) slots x 4 channel-quad lanes = 512
 
 // CACHED: sampling coordinates come from the per-sequence cache `fgrid` ([nsets][V][F0*F1*F2][2], the reference's
 // cached grid) instead of being recomputed: 2 coalesced 8-byte loads per lane and view replace ~230 VALU
 // instructions (the projection was ~45 % of the kernel's VALU work).
 template <int NVL, bool CACHED>   // NVL = channel quads per lane: ceil(JP/16)
-__global__ void __launch_bounds__(kTriThreads, NVL == 1 ? 4 : 2)     // NVL 1: <= 128 VGPRs, two workgroups per CU
+__global__ void __launch_bounds__(kTriThreads, 4)     // <= 128 VGPRs: two workgroups (2 x 8 waves) per CU
 k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
                        const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
                        const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
                        const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, int cap_px, FvpGeom g,
                        const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes) {
+  constexpr int BZ = NVL == 1 ? 32 : 16;            // z extent of the voxel block
+  constexpr int VPT = BZ / 4;                        // voxels per thread: z = zs + 4 i
+  constexpr int OWN = VPT / 4;                       // voxels a lane projects per view (i = q + 4 k)
   HIP_DYNAMIC_SHARED(float, smem)
   // LDS: two tiles of cap_px * JP floats (view v lives in tile v & 1; tile 0 is aliased by the block's plane
   // cells after the last view) | 3 x 4 ints of rectangle state (view v uses slot v % 3)
@@ -144,13 +143,13 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
   const unsigned m_qn = unsigned((1ull << 32) / unsigned(qn)) + 1u;
 
   // this lane's two voxels (i = q and q + 4) of view v: projection, tap origin; contribution to view v's rectangle
-  struct Own { int xy[kOwn]; int inside[kOwn]; float w[kOwn][4]; };
+  struct Own { int xy[OWN]; int inside[OWN]; float w[OWN][4]; };
   // CACHED: coordinates of view v are loaded one iteration ahead (load_coords) so their latency hides behind
   // the sampling of the previous view
-  float2 crd[kOwn];
+  float2 crd[OWN];
   auto load_coords = [&](int v, int gz0) {
 #pragma unroll
-    for (int k = 0; k < kOwn; ++k) {
+    for (int k = 0; k < OWN; ++k) {
       const int gzi = gz0 + zs + 4 * (q + 4 * k);
       crd[k] = gcol[size_t(v) * nfine + (gzi < F2 ? gzi : F2 - 1)];
     }
@@ -158,7 +157,7 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
   auto project = [&](int v, int gz0, Own& o) {
     int mnx = INT_MIN, mxx = INT_MIN, mny = INT_MIN, mxy = INT_MIN;     // (-min, max) pairs
 #pragma unroll
-    for (int k = 0; k < kOwn; ++k) {
+    for (int k = 0; k < OWN; ++k) {
       const int gzi = gz0 + zs + 4 * (q + 4 * k);
       const bool vin = col_in && gzi < e2;
       o.inside[k] = 0;
@@ -240,12 +239,12 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
     return d;
   };
 
-  for (int gz0 = s2; gz0 < e2; gz0 += kBZ) {                             // z blocks of the window
+  for (int gz0 = s2; gz0 < e2; gz0 += BZ) {                             // z blocks of the window
     if (t < 12) rect[t] = INT_MIN;
     __syncthreads();
-    float acc[kVPT][NVL][4];
+    float acc[VPT][NVL][4];
 #pragma unroll
-    for (int i = 0; i < kVPT; ++i)
+    for (int i = 0; i < VPT; ++i)
 #pragma unroll
       for (int n = 0; n < NVL; ++n)
 #pragma unroll
@@ -297,7 +296,7 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
           }
         };
 #pragma unroll
-        for (int k = 0; k < kOwn; ++k) {
+        for (int k = 0; k < OWN; ++k) {
           const TapL mine = finish(cur, k, rcur);
           { const TapL tv = quad_bcast_l<0>(mine); sample(tv, acc[4 * k + 0]); }
           { const TapL tv = quad_bcast_l<1>(mine); sample(tv, acc[4 * k + 1]); }
@@ -312,9 +311,9 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
     //      below), then into the global planes
     __syncthreads();
     int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JP]
-    int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][kBZ][JP]
-    int* cyz = cxz + kBX * kBZ * JP;                                     // [kBY][kBZ][JP]
-    const int ncell = (kBX * kBY + (kBX + kBY) * kBZ) * JP;              // <= cap_px * JP (checked by the host)
+    int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][BZ][JP]
+    int* cyz = cxz + kBX * BZ * JP;                                     // [kBY][BZ][JP]
+    const int ncell = (kBX * kBY + (kBX + kBY) * BZ) * JP;              // <= cap_px * JP (checked by the host)
     for (int i = t; i < ncell; i += NT) cxy[i] = 0;
     __syncthreads();
 #pragma unroll
@@ -324,13 +323,13 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
         const int ch = 16 * n + 4 * q + c;
         float mz = 0.0f;
 #pragma unroll
-        for (int i = 0; i < kVPT; ++i) {
+        for (int i = 0; i < VPT; ++i) {
           const float val = clampf(__fdiv_rn(acc[i][n][c], nv), 0.0f, 1.0f);
           mz = fmaxf(mz, val);
           if (val > 0.0f && ch < JP) {
             const int z = zs + 4 * i;
-            atomicMax(&cxz[(xx * kBZ + z) * JP + ch], __float_as_int(val));
-            atomicMax(&cyz[(yy * kBZ + z) * JP + ch], __float_as_int(val));
+            atomicMax(&cxz[(xx * BZ + z) * JP + ch], __float_as_int(val));
+            atomicMax(&cyz[(yy * BZ + z) * JP + ch], __float_as_int(val));
           }
         }
         // the four zs lanes of a column sit 4 lanes apart inside one DPP row: rotate by 4 and 8
@@ -347,8 +346,8 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
       if (vv > 0 && gx0 + cx < e0 && gy0 + cy < e1)
         atomicMax(reinterpret_cast<int*>(&pxy[size_t(ch) * CC + (gx0 + cx - tl0) * C + (gy0 + cy - tl1)]), vv);
     }
-    for (int i = t; i < (kBX + kBY) * kBZ * J; i += NT) {                // xz then yz rows: z fastest
-      const int ch = i / ((kBX + kBY) * kBZ), r = i - ch * ((kBX + kBY) * kBZ), a = r / kBZ, z = r - a * kBZ;
+    for (int i = t; i < (kBX + kBY) * BZ * J; i += NT) {                // xz then yz rows: z fastest
+      const int ch = i / ((kBX + kBY) * BZ), r = i - ch * ((kBX + kBY) * BZ), a = r / BZ, z = r - a * BZ;
       if (gz0 + z < e2) {
         const int vv = cxz[r * JP + ch];                                 // rows kBX.. continue into cyz
         if (vv > 0) {
