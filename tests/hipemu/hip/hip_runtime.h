@@ -228,6 +228,18 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) 
   return hipemu_shfl_from(src, from);
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
+// v_permlane32_swap_b32 vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src; returns {vdst, src}
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_u32x2 hipemu_permlane32_swap(unsigned vdst, unsigned src, bool, bool) {
+  const int l = hipemu::cur->lane;
+  const unsigned src_lo = (unsigned)hipemu_shfl_from((int)src, l & 31);          // src of lane l - 32 (for upper lanes)
+  const unsigned dst_hi = (unsigned)hipemu_shfl_from((int)vdst, (l & 31) + 32);   // vdst of lane l + 32 (for lower lanes)
+  hipemu_u32x2 r;
+  r[0] = l < 32 ? vdst : src_lo;
+  r[1] = l < 32 ? dst_hi : src;
+  return r;
+}
+#define __builtin_amdgcn_permlane32_swap hipemu_permlane32_swap
 // the value is wave-uniform wherever the kernels use it
 static inline int hipemu_readfirstlane(int v) { return v; }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
