@@ -9,13 +9,17 @@
 //   D         : lane l holds cout column l&31 and pixel rows (r&3) + 8*(r>>2) + 4*(l>>5): 32 lanes
 //               store 32 consecutive channels of one pixel = 64 contiguous bytes of NHWC
 //
-// Workgroup = 4 waves (2 x 2), tile 128 pixels x 128 couts (64 for the 64-channel layers), k chunks
-// of 64 through one LDS buffer (37 KB: four workgroups per CU) with a 144-byte row pitch (conflict-free
-// b128 reads); the next chunk's global loads (branch-free, address-clamped) are in flight in registers
-// while the current one is multiplied.  A per-launch tap table
-// (dy, dx) covers strided convs and the four parity classes of ConvTranspose(k4, s2, p1) with the
-// same kernel; the last layer writes fp32 heatmaps directly in the channels-last layout the
-// projection kernels read (and / or NCHW, the reference's layout).
+// Two kernels share that formulation:
+//   k_bb_conv<BN>      4 waves (2 x 2), tile 128 pixels x 128 couts (64 for the 64-channel layers), k chunks of 64
+//                      through one LDS buffer (37 KB: four workgroups per CU) with a 144-byte row pitch (conflict-free
+//                      b128 reads); the next chunk's global loads (branch-free, address-clamped) are in flight in
+//                      registers while the current one is multiplied.  Stem, 64-cout layers, unfused heatmap layer.
+//   k_bb_conv_dma<BN>  8 waves, 256 pixels x 256 / 128 couts, both operand tiles through the LDS-DMA into two
+//                      swizzled slots, per-lane addressing hoisted out of the k loop (every layer with >= 64 stored
+//                      input channels and >= 128 couts; comment at the kernel).
+// A per-launch tap table (dy, dx) covers strided convs and the four parity classes of ConvTranspose(k4, s2, p1) with
+// the same kernels; the heatmap layer writes fp32 heatmaps directly in the channels-last layout the projection
+// kernels read (and / or NCHW, the reference's layout) - from the epilogue of the last transposed conv when fused.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
