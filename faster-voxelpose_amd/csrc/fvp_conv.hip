@@ -26,6 +26,11 @@
 
 #include "fvp_common.h"
 
+// waves per SIMD the 1x1 / transposed-conv kernels are compiled for: they are HBM-bound, three waves (<= 168 VGPRs)
+// measured 11 us faster than two on the 64 -> 32 transposed conv, four spill
+#ifndef FVP_CONV_1X1_OCC
+#define FVP_CONV_1X1_OCC 3
+#endif
 namespace fvp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -563,7 +568,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&a
 // for both taps and the outputs leave as float2 (the tap-per-launch form reads it four times and
 // stores single floats at stride 2).
 template <int KH, int KW, int CB, int PB, bool PAIR = false, bool TPAIR = false>
-__global__ void __launch_bounds__(256, 2) k_conv_dma(ConvArgs a) {
+__global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_conv_dma(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
   constexpr int KT = PAIR ? KW + 1 : KW;             // taps per kernel row in the packed layout
   constexpr int KK = KH * KT;
