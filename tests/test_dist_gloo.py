@@ -118,3 +118,32 @@ def test_sharded_gather_equals_single_process_and_never_fences_the_pipeline():
     x = _fake_hot_path(torch.arange(0, 8, dtype=torch.float32))
     assert D.ResultGatherer(1).gather(x) is x
     assert D.shard_frames(8, 2, 1) == (4, 8)
+
+
+def _worker_always(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from faster_voxelpose_amd.core import distributed as D
+    log = []
+    comm = _LogStream("comm", log)
+    gat = D.ResultGatherer(1, stream=comm, stream_ctx=_Ctx, always=True)
+    x = _fake_hot_path(torch.arange(0, 8, dtype=torch.float32))
+    out = gat.gather(x, "done0")
+    gat.synchronize()
+    q.put((out.clone(), out.data_ptr() != x.data_ptr(), log))
+    dist.destroy_process_group()
+
+
+def test_forced_gather_at_world_size_one_runs_the_collective():
+    """``always=True`` (bench.py's FVP_BENCH_FORCE_DIST): the whole N > 1 path - communication stream, event
+    wait, all_gather into a ring buffer - runs with a single rank too."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_worker_always, args=(29617, q))
+    p.start()
+    out, copied, log = q.get()
+    p.join(60)
+    assert p.exitcode == 0
+    assert torch.equal(out, _fake_hot_path(torch.arange(0, 8, dtype=torch.float32))) and copied
+    assert ("comm", "wait_event", "done0") in log
