@@ -29,6 +29,7 @@ constexpr int kWFloats = 12288;                       // floats per weight buffe
 constexpr int kNB = 2;                               // ring depth: chunk c+1 streams in while chunk c computes
 constexpr int kKS = 4;                               // K split across waves
 constexpr int kNT1 = 256 * kKS;                      // threads per workgroup (4 cout blocks x kKS)
+constexpr int kEpiFloats = 512;                      // LDS floats per epilogue-vector slot (3 * coutp <= 384, whole DMA pieces)
 
 // One pipeline step of the fused stack: `nrows` weight rows (row = (ci, tap), coutp floats each) of
 // op `op` starting at row0, or a weight-less step (pool / slot clearing) when nrows == 0.
@@ -75,6 +76,7 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
   const int l31 = lane & 31, half = lane >> 5;
   const int plane = blockIdx.x;
   float* const wbufs = lds + a.lds_floats;           // two weight buffers behind the activation arena
+  float* const epis = wbufs + kNB * kWFloats;        // two slots of epilogue vectors (op parity)
 
   // LDS-DMA of chunk c's weight rows into ring slot c % kNB; returns this wave's instruction count
   auto stage = [&](int c) -> int {
@@ -92,6 +94,19 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
       if (it < nq)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + it * 4),
                                          (__attribute__((address_space(3))) void*)(dst + g * 256), 16, 0, 0);
+    }
+    // the op's bias | scale | shift vectors (3 * coutp <= 384 floats) ride along with its first weight chunk: the
+    // epilogue used to fetch them from global memory after the last MFMA, ~2 us of exposed latency per op
+    if (ch.first && wv == 4 * kKS - 1) {
+      const int ne = 3 * op.coutp / 4;                // quads
+      float* edst = epis + (ch.op & 1) * kEpiFloats;
+      for (int g = 0; g * 64 < ne; ++g) {
+        const int it = g * 64 + lane;
+        ++n;
+        if (it < ne)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.params + op.e_off + it * 4),
+                                           (__attribute__((address_space(3))) void*)(edst + g * 256), 16, 0, 0);
+      }
     }
     return n;
   };
@@ -190,7 +205,7 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
         const int dw = a.buf_w[op.dst];
         const bool final_op = ch.op == a.nops - 1;
         float* dst = lds + a.buf_off[op.dst];
-        const float* bias = a.params + op.e_off;
+        const float* bias = epis + (ch.op & 1) * kEpiFloats;   // staged with the op's first chunk
         const float* scale = bias + op.coutp;
         const float* shift = bias + 2 * op.coutp;
         const bool relu = op.flags & FVP_EPI_RELU, has_res = op.flags & FVP_EPI_RES;
@@ -249,6 +264,7 @@ extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const
     const int Lo = op.kind == FVP_OP_CONVT2 ? 2 * op.w : (op.kind == FVP_OP_POOL2 ? op.w / 2 : op.w);
     FVP_LIMIT(Lo <= 24);
     if (op.kind == FVP_OP_CONV) FVP_LIMIT(op.kh == 1 && (op.kw == 1 || op.kw == 3 || op.kw == 7));
+    FVP_LIMIT(op.e_off % 4 == 0 && op.coutp % 4 == 0);   // the epilogue vectors are staged by 16-byte LDS-DMA items
     chan[op.src] = op.cin;
     len[op.src] = op.w;
     chan[op.dst] = op.cout;
@@ -325,7 +341,7 @@ extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const
   a.params = params;
   a.in = in;
   a.out = out;
-  const size_t lds = size_t(total + kNB * kWFloats) * sizeof(float);
+  const size_t lds = size_t(total + kNB * kWFloats + 2 * kEpiFloats) * sizeof(float);
   FVP_LIMIT(lds <= 160 * 1024);
   static LdsOptIn optin;
   if (lds_opt_in(optin, reinterpret_cast<const void*>(&k_conv1d_fused), lds > 64 * 1024 ? 160 * 1024 : 0)) return FVP_ELIMIT;

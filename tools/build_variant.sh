@@ -11,7 +11,7 @@ objs=()
 for s in fvp_capi fvp_project fvp_conv fvp_conv1d_fused fvp_proposal fvp_joint fvp_heatmap fvp_backbone; do
   o="$out/obj_$name/$s.o"
   extra=(-ffp-contract=off); [[ "$s" == "fvp_conv" ]] && extra=()
-  if [[ "$s" == "fvp_conv" || "$s" == "fvp_project" || "$s" == "fvp_backbone" || ! -f "$csrc/$s.o" ]]; then
+  if [[ "$s" == "fvp_conv" || "$s" == "fvp_conv1d_fused" || "$s" == "fvp_project" || "$s" == "fvp_backbone" || ! -f "$csrc/$s.o" ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "${extra[@]}" "$@" -c "$csrc/$s.hip" -o "$o" &
   else
     cp "$csrc/$s.o" "$o"
