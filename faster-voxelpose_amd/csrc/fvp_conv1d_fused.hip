@@ -13,7 +13,10 @@
 // op the kKS partial tiles are added in the fixed order ks = 0, 1, ... through the just-consumed ring slot.
 // Measured (80 columns): 270 us with one wave per cout block, 238 us with kKS = 4; a deeper ring of smaller
 // slots (kNB = 4 x 24 KB, kKS = 2) is slower (269 us): the cost is per chunk (~3 us: scalar descriptor loads,
-// 16-wave rendezvous), not DMA latency.
+// 16-wave rendezvous), not DMA latency.  Ablations at 80 columns (231 us): without the vmcnt waits 230 (the weight
+// DMA is fully hidden), without the MFMA loop 134, skeleton alone (DMA + rendezvous) 41; requesting the operands
+// of the next channel pair before the MFMAs of the current one changes nothing (236): what is left is the 25
+// dependent op steps (K-slice reduction + epilogue, ~4 us each) and the 32-wide MFMA on 5-20 useful columns.
 // Deterministic; differs from the generic interpreter's single k-ordered chain only in rounding.
 #include <hip/hip_runtime.h>
 
