@@ -104,6 +104,10 @@ def load():
                 f"{LIB_PATH} not found: the HIP extension is required (there is no CPU fallback). "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`faster-voxelpose_amd/csrc/build.sh`.")
+        # PyTorch ships its own HIP runtime; it has to be the one already in the process when the library (which
+        # needs libamdhip64 by soname) is loaded - with the system copy loaded first, the two runtimes both try to
+        # own the device and every launch fails with "no ROCm-capable device"
+        import torch  # noqa: F401
         _lib = bind(C.CDLL(LIB_PATH))
         if _lib.fvp_version() != ABI_VERSION:
             raise FvpError("libfvp_hip.so ABI version mismatch (rebuild with faster-voxelpose_amd/csrc/build.sh)")
