@@ -371,9 +371,16 @@ def main():
                                  else "heatmaps resident in HBM")},
             "mpjpe_vs_ref_mm": mpjpe, "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }
-        print(json.dumps(line))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST line of stdout: RCCL prints a version banner through C stdio (buffered until
+        # exit when stdout is a pipe), so flush the C streams before printing
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
