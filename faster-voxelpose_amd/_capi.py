@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfvp_hip.so"
-ABI_VERSION = 3            # include/fvp.h FVP_ABI_VERSION
+ABI_VERSION = 4            # include/fvp.h FVP_ABI_VERSION
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 FVP_CAM_FLOATS = 24
@@ -73,6 +73,7 @@ SIGNATURES = {
     "fvp_bb_input": [_P, _P, _I, _I, _I, _I, _P],
     "fvp_bb_pack": [_P, _P, _P, _P, _P, _P, _F, C.POINTER(FvpBbOp), _P, _P, _P],
     "fvp_bb_run": [C.POINTER(FvpBbOp), _I, _P, _P, C.POINTER(_P), _I, _I, _P, _I, _P, _P],
+    "fvp_bb_tune": [C.POINTER(FvpBbOp), _I, _P, _P, C.POINTER(_P), _I, _I, _P],
     "fvp_prof_enable": [_I],
     "fvp_prof_read": [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
     "fvp_prof_reset": [],

@@ -307,7 +307,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {          /
 }
 
 template <int BN, int BK, int NSLOT, bool FUSE = false>
-__global__ void __launch_bounds__(512, 2) k_bb_conv_dma(BbConvArgs a, const uint16_t* __restrict__ zeros) {
+__global__ void __launch_bounds__(512, BN == 128 ? 4 : 2) k_bb_conv_dma(BbConvArgs a, const uint16_t* __restrict__ zeros) {
   constexpr int BM = 256, ROWB = 2 * BK;                             // LDS row = one k chunk of a pixel / cout: 128 or 64 bytes
   constexpr int GPR = BK / 8;                                        // 16-byte k groups per row
   constexpr int SLOTB = (BM + BN) * ROWB;                            // bytes per slot
@@ -367,12 +367,17 @@ __global__ void __launch_bounds__(512, 2) k_bb_conv_dma(BbConvArgs a, const uint
   // k order: channel block outermost, taps innermost -- consecutive chunks re-read the same activation rows shifted
   // by one tap, while they are still in the XCD's L2 (tap-major order touched them again only Cinp / 64 chunks of
   // 32 CUs x 64 KB later: beyond a 4 MB L2)
-  int st_tap = 0, st_c0 = 0;
+  // A 32-wide chunk is one half of a (64-channel block, tap) step, halves innermost: every tile configuration then
+  // adds the products of an output in exactly the same order (the per-op choice of fvp_bb_tune never changes a bit).
+  int st_tap = 0, st_c0 = 0, st_half = 0;
   auto stage = [&](int chunk) {
-    const int tap = st_tap, c0 = st_c0;
-    if (++st_tap == a.ntaps) {
-      st_tap = 0;
-      st_c0 += BK;
+    const int tap = st_tap, c0 = st_c0 + st_half * BK;
+    if (BK == 64 || ++st_half == 64 / BK) {
+      st_half = 0;
+      if (++st_tap == a.ntaps) {
+        st_tap = 0;
+        st_c0 += 64;
+      }
     }
     const int kk = tap * a.Cinp + c0;                 // position in the packed weights [cout][tap][cin]
     const int soff = a.toff[(tap0 + tap) & 31] + c0;  // wave-uniform element offset of (tap, c0)
@@ -749,13 +754,12 @@ template <int BN, int BK, int NSLOT, bool FUSE = false>
 static int bb_launch_dma(const BbConvArgs& a, int M, hipStream_t s, const uint16_t* zeros) {
   constexpr size_t lds_max = size_t(NSLOT) * (256 + BN) * 2 * BK;
   constexpr size_t lds_ep = 8 * 64 * 36 * sizeof(float) + (FUSE ? 4 * 64 * 32 * sizeof(float) : 0);   // staging (+ wn reduction)
-  static_assert(lds_max >= lds_ep, "epilogue staging fits the ring");
   // a short k loop touches only its first chunks' slots: less LDS = more workgroups per CU for the 1x1 expansions
   const size_t used = size_t(std::min(NSLOT, a.K / BK)) * (256 + BN) * 2 * BK;
   const size_t lds = std::max(used, lds_ep);
   static LdsOptIn optin;
   auto k = &k_bb_conv_dma<BN, BK, NSLOT, FUSE>;
-  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds_max)) return e;
+  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds_max > lds_ep ? lds_max : lds_ep)) return e;
   const int nmt = ceil_div(M, 256), nct = a.Coutp / BN;
   hipLaunchKernelGGL(k, dim3(unsigned(8 * ceil_div(nmt, 8) * nct * a.ncls)), dim3(512), lds, s, a, zeros);
   return launch_status();
@@ -786,7 +790,15 @@ static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const 
       const bool small_k = a.K == 64 && a.res;
       if (!(r128 < r256 || small_k)) bn = 256;
     }
-    return bn == 256 ? bb_launch_dma<256, 64, 2>(a, M, s, zeros) : bb_launch_dma<128, 64, 2>(a, M, s, zeros);
+    // tile configuration chosen by fvp_bb_tune for this op (bits 8-9 of flags), else the heuristic above.
+    // 1: 256 couts, 64-wide chunks; 2: 128 couts, 64-wide chunks; 3: 128 couts, 32-wide chunks (73.7 KB of LDS and
+    // <= 128 VGPRs: two workgroups per CU, one's epilogue overlaps the other's k loop).  All three walk k in the same
+    // order with the same MFMA: the choice never changes a result bit.
+    int cfg = (op.flags >> FVP_BB_CFG_SHIFT) & 3;
+    if (cfg == 1 && op.coutp % 256 != 0) cfg = 0;
+    if (cfg == 0) cfg = bn == 256 ? 1 : 2;
+    return cfg == 1 ? bb_launch_dma<256, 64, 2>(a, M, s, zeros)
+                    : cfg == 2 ? bb_launch_dma<128, 64, 2>(a, M, s, zeros) : bb_launch_dma<128, 32, 2>(a, M, s, zeros);
   }
   const bool wide = op.coutp % 128 == 0;
   dim3 grid(ceil_div(M, 128), op.coutp / (wide ? 128 : 64), a.ncls);
@@ -906,4 +918,50 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
     }
   }
   return 0;
+}
+
+// Per-op choice of the LDS-DMA kernel's tile configuration by measurement: every conv / transposed conv that the
+// kernel serves is run alone with each configuration (one warm-up + three timed launches, HIP events on `s`) and
+// the fastest goes into bits 8-9 of its flags.  The activation buffers are only scratch here.  Which tile shape
+// wins depends on how the launch fills the 256 CUs and on whether the op is HBM- or MFMA-bound; the candidates
+// compute identical bits, so tuning never changes results.
+extern "C" int fvp_bb_tune(FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs, int nbufs,
+                           int N, fvp_stream_t s) {
+  FVP_REQUIRE(ops && wblob && eblob && bufs && nops >= 0 && N >= 0);
+  if (N == 0) return 0;
+  hipStream_t st = as_stream(s);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_status() ? launch_status() : FVP_EINVAL;
+  int rc = 0;
+  for (int i = 0; i < nops && !rc; ++i) {
+    FvpBbOp& op = ops[i];
+    op.flags &= ~(3 << FVP_BB_CFG_SHIFT);
+    if ((op.kind != FVP_BB_CONV && op.kind != FVP_BB_DECONV) || (op.flags & (FVP_BB_OUT_HEAT | FVP_BB_STEM)) || op.dst < 0 ||
+        op.cinp % 64 != 0 || op.coutp % 128 != 0)
+      continue;
+    float best = 0.0f;
+    int best_cfg = 0;
+    for (int cfg = 1; cfg <= 3 && !rc; ++cfg) {
+      if (cfg == 1 && op.coutp % 256 != 0) continue;
+      FvpBbOp one = op;
+      one.flags |= cfg << FVP_BB_CFG_SHIFT;
+      rc = fvp_bb_run(&one, 1, wblob, eblob, bufs, nbufs, N, nullptr, 0, nullptr, s);            // warm-up
+      if (rc) break;
+      hipEventRecord(e0, st);
+      for (int r = 0; r < 3 && !rc; ++r) rc = fvp_bb_run(&one, 1, wblob, eblob, bufs, nbufs, N, nullptr, 0, nullptr, s);
+      hipEventRecord(e1, st);
+      if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = FVP_EINVAL;
+      if (rc) break;
+      float ms = 0.0f;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (best_cfg == 0 || ms < best) {
+        best = ms;
+        best_cfg = cfg;
+      }
+    }
+    if (!rc) op.flags |= best_cfg << FVP_BB_CFG_SHIFT;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return rc;
 }

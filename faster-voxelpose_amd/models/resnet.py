@@ -9,6 +9,7 @@ epilogue together with the residual add and ReLU).  ``forward_channels_last`` re
 heatmaps directly in the ``[N, H*W, JP]`` staging layout the projection kernels read.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -43,6 +44,9 @@ class PoseResNet(ParamTree):
         self._declare()
         self.__dict__["_dirty"] = True
         self.__dict__["_plans"] = {}
+        # per-(image size, batch) choice of the conv tile configuration by measurement (fvp_bb_tune); FVP_BB_NO_TUNE=1
+        # keeps the built-in heuristic
+        self.__dict__["autotune"] = not os.environ.get("FVP_BB_NO_TUNE")
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_dirty())
 
     # ---- parameters (registration order = the reference's module order) ------------------------------------------
@@ -159,7 +163,7 @@ class PoseResNet(ParamTree):
                 taps = 28 if o.get("stem") else (4 if o["kind"] == capi.BB_DECONV else k * k)
                 w_off += (4 if o["kind"] == capi.BB_DECONV else 1) * coutp * taps * cin_buf
                 e_off += 2 * coutp
-        plan = dict(ops=arr, names=names, shapes=shapes, w_elems=w_off, e_elems=e_off, out_hw=(oh, ow))
+        plan = dict(ops=arr, names=names, shapes=shapes, w_elems=w_off, e_elems=e_off, out_hw=(oh, ow), tuned={})
         self._plans[(H, W)] = plan
         return plan
 
@@ -227,7 +231,15 @@ class PoseResNet(ParamTree):
         cl = torch.empty((N, oh * ow, JP), dtype=torch.float32, device=dev) if want_cl else None
         nchw = torch.empty((N, J, oh, ow), dtype=torch.float32, device=dev) if want_nchw else None
         arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
-        rc = self.lib.fvp_bb_run(plan["ops"], len(plan["ops"]), C.c_void_p(self._wblob.data_ptr()),
+        if dev.type == "cuda" and self.autotune and N not in plan["tuned"]:
+            # once per (image size, batch): time every conv with each tile configuration of the large-tile kernel
+            # and keep the fastest (the configurations compute identical bits; ~100 ms, activation buffers as scratch)
+            ops = plan["tuned"][N] = (capi.FvpBbOp * len(plan["ops"]))(*plan["ops"])
+            rc = self.lib.fvp_bb_tune(ops, len(ops), C.c_void_p(self._wblob.data_ptr()), C.c_void_p(self._eblob.data_ptr()),
+                                      arr, len(bufs), N, s)
+            capi.check(self.lib, rc, "fvp_bb_tune")
+        ops_run = plan["tuned"].get(N, plan["ops"])
+        rc = self.lib.fvp_bb_run(ops_run, len(plan["ops"]), C.c_void_p(self._wblob.data_ptr()),
                                  C.c_void_p(self._eblob.data_ptr()), arr, len(bufs), N,
                                  C.c_void_p(cl.data_ptr()) if cl is not None else None, JP,
                                  C.c_void_p(nchw.data_ptr()) if nchw is not None else None, s)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FVP_ABI_VERSION 3
+#define FVP_ABI_VERSION 4
 #define FVP_MAX_VIEWS 8
 #define FVP_CAM_FLOATS 24 /* R[9] T[3] fx fy cx cy k[3] p[2] + 3 pad */
 #define FVP_MAX_JOINTS 32
@@ -248,7 +248,8 @@ int fvp_rasterise_heatmaps(const double* joints, const int32_t* num_people, int 
  * kernels read) and / or NCHW [N][J][H][W] (the reference's layout). */
 enum { FVP_BB_CONV = 0, FVP_BB_MAXPOOL = 1, FVP_BB_DECONV = 2 };
 enum { FVP_BB_OUT_HEAT = 8,      /* with FVP_EPI_RELU = 1 in `flags` */
-       FVP_BB_STEM = 16 };       /* the 7x7 / stride-2 stem on a <= 4-channel image: pixel-pair form (fvp_backbone.hip) */
+       FVP_BB_STEM = 16,         /* the 7x7 / stride-2 stem on a <= 4-channel image: pixel-pair form (fvp_backbone.hip) */
+       FVP_BB_CFG_SHIFT = 8 };   /* flags bits 8-9: tile configuration chosen by fvp_bb_tune (0 = built-in heuristic) */
 typedef struct FvpBbOp {
   int32_t kind;
   int32_t src, dst, res;      /* activation buffer ids (dst = -1 for the heatmap op, res = -1 if unused) */
@@ -271,6 +272,11 @@ int fvp_bb_pack(const float* weight, const float* bias, const float* bn_gamma, c
  * zero (e_off >= 64): the LDS-DMA of the large-tile kernel reads them for padding. */
 int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs, int nbufs,
                int N, float* heat_cl, int heat_jp, float* heat_nchw, fvp_stream_t s);
+/* optional, once per (op list, N): times every conv op with each tile configuration of the large-tile kernel and
+ * records the fastest in its flags (the configurations compute identical bits).  Synchronises `s`; the activation
+ * buffers are used as scratch. */
+int fvp_bb_tune(FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs, int nbufs, int N,
+                fvp_stream_t s);
 
 /* ---- measurement hooks (bench.py roofline leg) -----------------------------------------------------
  * fvp_prof_enable(1): kernel classes are bracketed by hipEvents on the stream they are launched

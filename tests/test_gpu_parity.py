@@ -455,6 +455,56 @@ def test_backbone_tile_shapes_give_identical_heatmaps(monkeypatch):
     assert float((y2 - y0).norm() / y0.norm()) < 2e-2 and not torch.equal(y2, torch.zeros_like(y2))
 
 
+@pytest.mark.gpu
+def test_backbone_tile_configurations_are_bit_identical_per_op():
+    """fvp_bb_tune picks one of three tile configurations of the LDS-DMA conv kernel per op by timing them.  That is
+    only legitimate if the choice cannot change a result: every eligible op of the Pose-ResNet-50 plan, run alone
+    on the same random bf16 inputs with each configuration, gives identical bits."""
+    import ctypes as C
+    from faster_voxelpose_amd import _capi as capi
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    m = RN.get(CFG.default_config()).to("cuda:0")
+    m.load_state_dict(S.fill_backbone_state_dict(m.state_dict(), seed=5))
+    m.autotune = False
+    N, H, W = 3, 160, 224
+    with torch.no_grad():
+        m(torch.rand(N, 3, H, W, device="cuda"))                       # packs the weights
+    plan = m._plan(H, W)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    bufs = []
+    for name in plan["names"]:
+        c, h, w = plan["shapes"][name]
+        bufs.append((torch.rand((N, h, w, c), device="cuda", generator=g) - 0.5).bfloat16())
+    arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    checked = 0
+    for op in plan["ops"]:
+        if op.kind == capi.BB_MAXPOOL or op.dst < 0 or op.cinp % 64 or op.coutp % 128:
+            continue
+        outs = []
+        for cfgv in ((1, 2, 3) if op.coutp % 256 == 0 else (2, 3)):
+            one = (capi.FvpBbOp * 1)(op)
+            one[0].flags = (op.flags & ~(3 << 8)) | (cfgv << 8)
+            bufs[op.dst].zero_()
+            capi.check(m.lib, m.lib.fvp_bb_run(one, 1, C.c_void_p(m._wblob.data_ptr()), C.c_void_p(m._eblob.data_ptr()), arr,
+                                               len(bufs), N, None, 0, None, s), "fvp_bb_run")
+            torch.cuda.synchronize()
+            outs.append(bufs[op.dst].clone())
+        assert outs[0].float().abs().max() > 0
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (op.cin, op.cout, op.kh, op.h, op.w)
+        checked += 1
+    assert checked >= 40
+    # and the tuner itself leaves the heatmaps untouched
+    x = torch.rand(N, 3, H, W, device="cuda")
+    with torch.no_grad():
+        y0 = m(x).clone()
+        m.autotune = True
+        y1 = m(x).clone()
+    assert N in plan["tuned"] and torch.equal(y0, y1)
+
+
 # ---- edge cases shared with the emulator suite (tests/edge_cases.py) ---------------------------------
 @pytest.mark.gpu
 def test_zero_batch_through_every_export():
