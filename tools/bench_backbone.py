@@ -32,7 +32,8 @@ def per_op(m, x, a):
     cl = torch.empty((N, plan["out_hw"][0] * plan["out_hw"][1], 16), device="cuda")
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot = 0.0
-    for i, op in enumerate(plan["ops"]):
+    ops = plan["tuned"].get(N, plan["ops"])               # the tile configurations fvp_bb_tune picked, if it ran
+    for i, op in enumerate(ops):
         one = (capi.FvpBbOp * 1)(op)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(4):
@@ -47,7 +48,7 @@ def per_op(m, x, a):
         tot += us
         fl = 0.0 if op.kind == 1 else 2.0 * op.cin * op.cout * (4 if op.kind == 2 else op.kh * op.kw) * op.oh * op.ow * N
         by = 2.0 * N * (op.cinp * op.h * op.w + op.cout * op.oh * op.ow * (2 if op.res >= 0 else 1))
-        print(f"  op{i:2d} kind {op.kind} {op.cin:4d}->{op.cout:4d} k{op.kh} s{op.stride} @{op.h}x{op.w}  {us:8.1f} us  "
+        print(f"  op{i:2d} kind {op.kind} cfg {(op.flags >> 8) & 3} {op.cin:4d}->{op.cout:4d} k{op.kh} s{op.stride} @{op.h}x{op.w}  {us:8.1f} us  "
               f"{fl / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s")
     print(f"  total {tot / 1e3:.2f} ms")
 
