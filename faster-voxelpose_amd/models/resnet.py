@@ -231,7 +231,7 @@ class PoseResNet(ParamTree):
         cl = torch.empty((N, oh * ow, JP), dtype=torch.float32, device=dev) if want_cl else None
         nchw = torch.empty((N, J, oh, ow), dtype=torch.float32, device=dev) if want_nchw else None
         arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
-        if dev.type == "cuda" and self.autotune and N not in plan["tuned"]:
+        if dev.type == "cuda" and self.autotune and N not in plan["tuned"] and not torch.cuda.is_current_stream_capturing():
             # once per (image size, batch): time every conv with each tile configuration of the large-tile kernel
             # and keep the fastest (the configurations compute identical bits; ~100 ms, activation buffers as scratch)
             ops = plan["tuned"][N] = (capi.FvpBbOp * len(plan["ops"]))(*plan["ops"])
