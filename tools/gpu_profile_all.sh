@@ -20,7 +20,7 @@ for spec in "1 1" "1 3" "2 3" "8 1" "8 2" "16 3" "32 3"; do
   timeout 300 python bench.py --steps 10 --warmup 3 --batch $1 --streams $2 --no-cpu-baseline > "$dst/${tag}_bench_b$1_s$2.json" 2>> "$out/bench_${tag}.err"
 done
 timeout 300 python tools/bench_backbone.py --images 40 --iters 3 --per-op > "$dst/${tag}_backbone_per_op.log" 2>&1
-for st in 1 2; do
+for st in 1 2 3; do
   timeout 300 python bench.py --backbone --steps 8 --warmup 2 --streams $st --no-cpu-baseline > "$dst/${tag}_bench_e2e_b8_s$st.json" 2>> "$out/bench_${tag}.err"
 done
 timeout 300 python tools/bench_conv.py --net conv_net --frames 8 --iters 10 > "$dst/${tag}_conv_per_op_p2pnet_b8.log" 2>&1
