@@ -33,11 +33,12 @@ class ResultGatherer:
     rank order.  On a GPU the collective runs on ``self.stream`` (a dedicated communication stream),
     ordered after ``ready`` (the event recorded when ``local`` was produced); the returned tensor is
     valid once ``synchronize()`` returns (or after ``self.stream`` in stream order).  With
-    ``world == 1`` the input is returned untouched and no stream is involved.
+    ``world == 1`` the input is returned untouched and no stream is involved.  Without ``ready`` the collective
+    is ordered behind everything already enqueued on the caller's current stream.
 
     ``stream`` / ``stream_ctx`` are injectable so the ordering contract can be tested without a GPU."""
 
-    def __init__(self, world, device=None, stream=None, stream_ctx=None, always=False):
+    def __init__(self, world, device=None, stream=None, stream_ctx=None, always=False, current_stream=None):
         self.world = int(world)
         self.always = bool(always)      # run the collective for world == 1 too (single-GPU check of the RCCL path)
         self.device = torch.device(device) if device is not None else None
@@ -49,6 +50,13 @@ class ResultGatherer:
         else:
             self.stream = _InlineStream()
         self._ctx = stream_ctx if stream_ctx is not None else (torch.cuda.stream if on_gpu and (self.world > 1 or self.always) else None)
+        # the stream a gather WITHOUT a completion event is ordered behind (the caller's current stream)
+        if current_stream is not None:
+            self._current = current_stream
+        elif isinstance(self.stream, _InlineStream) or not on_gpu:
+            self._current = None
+        else:
+            self._current = lambda: torch.cuda.current_stream(self.device)
         self._out = {}
         self._slot = 0
 
@@ -68,6 +76,11 @@ class ResultGatherer:
             return local
         if ready is not None:
             self.stream.wait_event(ready)               # the ONLY dependency: batch t -> gather t
+        elif self._current is not None:
+            # no completion event given: `local` was produced by work already enqueued on the caller's current
+            # stream (plain forward, hipGraph replay), so order the collective behind that stream.  The caller
+            # must not overwrite `local` before the gather has run (a graph's static output: pass a clone).
+            self.stream.wait_stream(self._current())
         out = self._buffer(local)
 
         def run():

@@ -1,24 +1,36 @@
 #!/usr/bin/env bash
 # Build the HIP library for gfx950 (cross-compiles without a GPU).  Output: ../libfvp_hip.so
+#   build.sh           incremental: a source is recompiled when it or any header is newer than its object
+#   build.sh --force   from scratch: every object is recompiled (objects shipped with a snapshot are ignored)
+# FVP_BUILD_FORCE=1 in the environment is the same as --force.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${here}/../libfvp_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+force="${FVP_BUILD_FORCE:-0}"
+[[ "${1:-}" == "--force" ]] && force=1
 srcs=(fvp_capi.hip fvp_project.hip fvp_conv.hip fvp_conv1d_fused.hip fvp_proposal.hip fvp_joint.hip fvp_heatmap.hip fvp_backbone.hip)
+hdrs=("${here}"/*.h "${here}/../../include/fvp.h")
 objs=()
+compiled=0
 for s in "${srcs[@]}"; do
   o="${here}/${s%.hip}.o"
-  if [[ ! -f "$o" || "$o" -ot "${here}/$s" || "$o" -ot "${here}/fvp_common.h" || "$o" -ot "${here}/fvp_geom.h" \
-        || "$o" -ot "${here}/../../include/fvp.h" || "$o" -ot "${here}/fvp_conv_wino.h" || "$o" -ot "${here}/fvp_project_lds.h" ]]; then
+  stale=$force
+  if [[ $stale == 0 ]]; then
+    [[ ! -f "$o" || "$o" -ot "${here}/$s" ]] && stale=1
+    for h in "${hdrs[@]}"; do [[ -f "$o" && "$o" -ot "$h" ]] && stale=1; done
+  fi
+  if [[ $stale == 1 ]]; then
     # geometry / proposal / fusion code mirrors the reference's separately-rounded fp32 ops:
     # no fma contraction there (HIP's __fmul_rn/__fadd_rn are plain operators); the MFMA conv
     # file keeps the default.
     extra=(-ffp-contract=off)
     [[ "$s" == "fvp_conv.hip" ]] && extra=()
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" -c "${here}/$s" -o "$o" &
+    compiled=$((compiled + 1))
   fi
   objs+=("$o")
 done
 wait
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
-echo "built $out"
+echo "built $out (${compiled} of ${#srcs[@]} objects recompiled$([[ $force == 1 ]] && echo ', forced'))"

@@ -765,12 +765,22 @@ static int bb_launch_dma(const BbConvArgs& a, int M, hipStream_t s, const uint16
   return launch_status();
 }
 
-static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const uint16_t* zeros) {
+// Diagnostic switches (tests flip them between calls): read ONCE per fvp_bb_run call, not per launch - a
+// backbone pass is ~60 launches, and getenv racing a setenv from another thread is undefined behaviour.
+struct BbSwitches {
+  bool no_big;          // FVP_BB_NO_BIG: the register-staged kernel only
+  int bn_cap;           // FVP_BB_DMA_BN: 128-cout tiles only
+  bool no_fuse_final;   // FVP_BB_NO_FUSE_FINAL: heatmap layer as its own launch
+  static BbSwitches read() {
+    const char* bn = getenv("FVP_BB_DMA_BN");
+    return {getenv("FVP_BB_NO_BIG") != nullptr, bn ? atoi(bn) : 256, getenv("FVP_BB_NO_FUSE_FINAL") != nullptr};
+  }
+};
+
+static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const uint16_t* zeros, const BbSwitches& sw) {
   const int M = a.N * a.OH * a.OW;
-  // diagnostics / tests (read per launch so that a test can switch them): the register-staged kernel only, or
-  // 128-cout tiles only
-  const bool no_big = getenv("FVP_BB_NO_BIG") != nullptr;
-  const int bn_cap = getenv("FVP_BB_DMA_BN") ? atoi(getenv("FVP_BB_DMA_BN")) : 256;
+  const bool no_big = sw.no_big;
+  const int bn_cap = sw.bn_cap;
   // LDS-DMA kernel: a k chunk of 64 inside one tap, plain bf16 NHWC output, offsets within 32 bits
   if (a.w2) {                                          // heatmap layer fused into this layer (eligibility: fvp_bb_run)
     for (int i = 0; i < a.ntaps * a.ncls; ++i) a.toff[i] = (int(a.dy[i]) * a.W + int(a.dx[i])) * a.Cinp;
@@ -815,6 +825,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       flops += 2.0 * ops[i].cin * ops[i].cout * (ops[i].kind == FVP_BB_DECONV ? 4.0 : double(ops[i].kh * ops[i].kw)) *
                ops[i].oh * ops[i].ow * N;
   ProfScope ps(FVP_K_BACKBONE, as_stream(s), flops, nops);
+  const BbSwitches sw = BbSwitches::read();
   for (int i = 0; i < nops; ++i) {
     const FvpBbOp& op = ops[i];
     FVP_REQUIRE(op.src >= 0 && op.src < nbufs && op.dst < nbufs && op.res < nbufs);
@@ -852,7 +863,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
     // the 1x1 heatmap layer behind a 256-cout layer is applied in that layer's epilogue: its 256-channel output
     // (the largest activation of the network) is never written or read
     bool fused_heat = false;
-    if (i + 1 < nops && !getenv("FVP_BB_NO_FUSE_FINAL") && !getenv("FVP_BB_NO_BIG")) {
+    if (i + 1 < nops && !sw.no_fuse_final && !sw.no_big) {
       const FvpBbOp& nx = ops[i + 1];
       if (nx.kind == FVP_BB_CONV && (nx.flags & FVP_BB_OUT_HEAT) && nx.src == op.dst && nx.res < 0 && nx.kh == 1 && nx.kw == 1 &&
           nx.stride == 1 && nx.pad == 0 && nx.cinp == 256 && op.coutp == 256 && op.cout == 256 && op.cinp % 64 == 0 && op.res < 0 &&
@@ -892,7 +903,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
       a.K = a.ntaps * op.cinp;
       a.ncls = 1;
       a.w = wblob + op.w_off;
-      if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
+      if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob), sw)) return rc;
       if (fused_heat) ++i;
     } else {
       // ConvTranspose(k4, s2, p1): output (2y + py, 2x + px) gathers input rows y + dy: py = 0 -> (ky 1, dy 0),
@@ -913,7 +924,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
         }
       }
       a.w = wblob + op.w_off;
-      if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob))) return rc;
+      if (int rc = bb_launch_conv(op, a, as_stream(s), reinterpret_cast<const uint16_t*>(eblob), sw)) return rc;
       if (fused_heat) ++i;
     }
   }

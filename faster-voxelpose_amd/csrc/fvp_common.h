@@ -70,7 +70,10 @@ inline int launch_status() {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is per (function, device): one
-// flag bit per device ordinal, so a second GPU used by the same process gets its own opt-in.
+// flag bit per device ordinal, so a second GPU used by the same process gets its own opt-in.  The opt-in is
+// remembered, not its size, so it always asks for the CU's whole 160 KB (the attribute is a cap on what a launch
+// may request, not an allocation): a later launch of the same kernel with a larger footprint (another joint
+// count / cube size in the same process) stays legal.
 struct LdsOptIn {
   unsigned long long done = 0;   // bit d: set on device d (benign race: setting twice is harmless)
 };
@@ -80,7 +83,7 @@ inline int lds_opt_in(LdsOptIn& st, const void* fn, size_t bytes) {
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   const unsigned long long bit = 1ull << (unsigned(dev) & 63u);
   if (__atomic_load_n(&st.done, __ATOMIC_RELAXED) & bit) return 0;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return static_cast<int>(e);
   __atomic_fetch_or(&st.done, bit, __ATOMIC_RELAXED);
   return 0;

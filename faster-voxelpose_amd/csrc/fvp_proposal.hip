@@ -13,9 +13,13 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
 }
 
 // One workgroup (1024 threads) per frame.  The map is copied to LDS once (coalesced), the 3x3 NMS reads its nine
-// neighbours from there, then N rounds of block arg-max over the kept values: every thread owns <= 16 cells in
-// registers, a round is a register scan + DPP-free shuffle tree + one 16-entry LDS stage.
-constexpr int kNmsThreads = 1024, kNmsCells = 16;   // up to 128 x 128 cells per frame
+// neighbours from there, then N rounds of block arg-max over the kept values.  REG = true (X * Y <= 16 384, every
+// shipped config): every thread owns <= 16 cells in registers, a round is a register scan + shuffle tree + one
+// 16-entry LDS stage.  REG = false (larger maps, up to the LDS limit of ~40 000 cells, e.g. 200 x 200): the keep
+// decisions are taken for all cells first (one bit per cell in two registers), then the map is overwritten in
+// place by keep * x and the rounds scan the thread's cells in LDS.  Same results either way.
+constexpr int kNmsThreads = 1024, kNmsCells = 16, kNmsMaxCellsLds = 64;
+template <bool REG>
 __global__ void __launch_bounds__(kNmsThreads)
 k_nms_topk(const float* __restrict__ hm, int X, int Y, int N, float* __restrict__ vals, long long* __restrict__ idx,
            long long* __restrict__ flat) {
@@ -26,32 +30,46 @@ k_nms_topk(const float* __restrict__ hm, int X, int Y, int N, float* __restrict_
   int* wi = reinterpret_cast<int*>(raw + n + 16);
   for (int i = t; i < n; i += kNmsThreads) raw[i] = m[i];
   __syncthreads();
-  // kept value of this thread's cells i = t + 1024 c (the host limits X * Y to kNmsCells * 1024)
+  // keep = (x == max).float(); keep * x   (core/proposal.py:23-25)
+  auto kept = [&](int i) {
+    const int x = i / Y, y = i - x * Y;
+    const float cv = raw[i];
+    float mx = cv;
+    for (int dx = -1; dx <= 1; ++dx)
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int xx = x + dx, yy = y + dy;
+        if (xx >= 0 && xx < X && yy >= 0 && yy < Y) mx = fmaxf(mx, raw[xx * Y + yy]);
+      }
+    return cv == mx;
+  };
+  // kept value of this thread's cells i = t + 1024 c
   float kv[kNmsCells];
+  if (REG) {
 #pragma unroll
-  for (int c = 0; c < kNmsCells; ++c) {
-    const int i = t + c * kNmsThreads;
-    kv[c] = -INFINITY;
-    if (i < n) {
-      const int x = i / Y, y = i - x * Y;
-      const float cv = raw[i];
-      float mx = cv;
-      for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int xx = x + dx, yy = y + dy;
-          if (xx >= 0 && xx < X && yy >= 0 && yy < Y) mx = fmaxf(mx, raw[xx * Y + yy]);
-        }
-      // keep = (x == max).float(); keep * x   (core/proposal.py:23-25)
-      kv[c] = __fmul_rn((cv == mx) ? 1.0f : 0.0f, cv);
+    for (int c = 0; c < kNmsCells; ++c) {
+      const int i = t + c * kNmsThreads;
+      kv[c] = -INFINITY;
+      if (i < n) kv[c] = __fmul_rn(kept(i) ? 1.0f : 0.0f, raw[i]);
     }
+  } else {
+    unsigned long long bits = 0;                // host: n <= kNmsMaxCellsLds * 1024
+    for (int c = 0, i = t; i < n; ++c, i += kNmsThreads) bits |= (unsigned long long)(kept(i) ? 1 : 0) << c;
+    __syncthreads();                            // every neighbourhood has been read: overwrite in place
+    for (int c = 0, i = t; i < n; ++c, i += kNmsThreads) raw[i] = __fmul_rn(((bits >> c) & 1) ? 1.0f : 0.0f, raw[i]);
+    // (each thread re-reads only its own cells below: no barrier needed)
   }
   for (int k = 0; k < N; ++k) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
+    if (REG) {
 #pragma unroll
-    for (int c = 0; c < kNmsCells; ++c) {
-      const int i = t + c * kNmsThreads;
-      if (i < n && better(kv[c], i, bv, bi)) { bv = kv[c]; bi = i; }
+      for (int c = 0; c < kNmsCells; ++c) {
+        const int i = t + c * kNmsThreads;
+        if (i < n && better(kv[c], i, bv, bi)) { bv = kv[c]; bi = i; }
+      }
+    } else {
+      for (int i = t; i < n; i += kNmsThreads)
+        if (better(raw[i], i, bv, bi)) { bv = raw[i]; bi = i; }
     }
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o);
@@ -73,9 +91,13 @@ k_nms_topk(const float* __restrict__ hm, int X, int Y, int N, float* __restrict_
       idx[(size_t(b) * N + k) * 2 + 0] = bi / X;
       idx[(size_t(b) * N + k) * 2 + 1] = bi % X;
     }
+    if (REG) {
 #pragma unroll
-    for (int c = 0; c < kNmsCells; ++c)
-      if (t + c * kNmsThreads == bi) kv[c] = -INFINITY;   // the owner retires the winner
+      for (int c = 0; c < kNmsCells; ++c)
+        if (t + c * kNmsThreads == bi) kv[c] = -INFINITY;   // the owner retires the winner
+    } else if ((bi & (kNmsThreads - 1)) == t) {
+      raw[bi] = -INFINITY;                       // the owner's own cell: visible to its next scan without a barrier
+    }
     __syncthreads();                              // wv / wi are rewritten next round
   }
 }
@@ -144,12 +166,15 @@ extern "C" int fvp_nms_topk(const float* hm2d, int B, int X, int Y, int N, float
                             fvp_stream_t s) {
   FVP_REQUIRE(hm2d && vals && idx && flat && B >= 0 && X > 0 && Y > 0 && N > 0);
   const size_t lds = size_t(X) * Y * 4 + 128;
-  FVP_LIMIT(lds <= 160 * 1024 && N <= X * Y && X * Y <= kNmsCells * kNmsThreads);
-  static LdsOptIn optin;
-  if (lds_opt_in(optin, reinterpret_cast<const void*>(&k_nms_topk), lds > 64 * 1024 ? 160 * 1024 : 0)) return FVP_ELIMIT;
+  // limit: the map + 32 words must fit the CU's 160 KB of LDS (X * Y <= 40 928, e.g. 200 x 200)
+  FVP_LIMIT(lds <= 160 * 1024 && N <= X * Y && X * Y <= kNmsMaxCellsLds * kNmsThreads);
+  const bool reg = X * Y <= kNmsCells * kNmsThreads;
+  auto k = reg ? &k_nms_topk<true> : &k_nms_topk<false>;
+  static LdsOptIn optin[2];
+  if (lds_opt_in(optin[reg], reinterpret_cast<const void*>(k), lds)) return FVP_ELIMIT;
   if (B == 0) return 0;
   ProfScope ps(FVP_K_OTHER, as_stream(s));
-  hipLaunchKernelGGL(k_nms_topk, dim3(B), dim3(kNmsThreads), lds, as_stream(s), hm2d, X, Y, N, vals,
+  hipLaunchKernelGGL(k, dim3(B), dim3(kNmsThreads), lds, as_stream(s), hm2d, X, Y, N, vals,
                      reinterpret_cast<long long*>(idx), reinterpret_cast<long long*>(flat));
   return launch_status();
 }

@@ -72,8 +72,10 @@ class HotPath:
         # project_individual.py:82-94; 164 MB for the Panoptic shape set): the fused tri-plane kernel then loads
         # 8 bytes per (voxel, view) instead of recomputing the projection.  Off above ~2 GB per camera set.
         self.cache_fine_grid = not self._injected     # (the CPU emulation of the kernels builds it too slowly for every test)
-        self.fine_grid_limit_bytes = 2 << 30
+        self.fine_grid_limit_bytes = 2 << 30           # per camera set
+        self.fine_grid_total_limit_bytes = 8 << 30     # all sets of this replica together (288 GB of HBM per GPU)
         self._fine_grid = None
+        self._fine_grid_key = None
         self.fine_axes = axes(cs.SPACE_SIZE, cs.SPACE_CENTER, self.fine)
         # center_grid [3, C*C, 2] (project_individual.py:37-40): xy at z0, xz at y0, yz at x0
         ia = axes(ins.SPACE_SIZE, cs.SPACE_CENTER, ins.VOXELS_PER_AXIS)
@@ -175,14 +177,21 @@ class HotPath:
 
     def fine_grid_cache(self, resize_transform, V):
         """[nsets, V, F0*F1*F2, 2] sampling coordinates of the fine grid for every uploaded camera set (built by
-        fvp_sample_grid, extended when a new sequence appears), or None when a set would exceed the limit."""
+        fvp_sample_grid, extended when a new sequence appears), or None when one set would exceed
+        ``fine_grid_limit_bytes`` or all sets together ``fine_grid_total_limit_bytes`` (the kernel then recomputes
+        the projection: same bits).  The cache belongs to one (resize_transform, V): it is rebuilt when
+        ``geom()`` re-derives the geometry, never silently reused."""
         n = self.fine[0] * self.fine[1] * self.fine[2]
-        if V * n * 8 > self.fine_grid_limit_bytes:
-            return None
         nsets = self._cams.shape[0]
+        if V * n * 8 > self.fine_grid_limit_bytes or nsets * V * n * 8 > self.fine_grid_total_limit_bytes:
+            self._fine_grid = None
+            return None
+        g = self.geom(resize_transform)
+        key = (tuple(g.rt), g.clamp_max, V)
+        if self._fine_grid is not None and self._fine_grid_key != key:
+            self._fine_grid = None                      # resize_transform changed: stale coordinates
         have = 0 if self._fine_grid is None else self._fine_grid.shape[0]
         if have < nsets:
-            g = self.geom(resize_transform)
             g.V = V
             new = torch.empty((nsets, V, n, 2), device=self.device)
             if have:
@@ -191,7 +200,7 @@ class HotPath:
             for i in range(have, nsets):
                 self._call("fvp_sample_grid", _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), self.fine[0], self.fine[1],
                            self.fine[2], _ptr(self._cams[i]), C.byref(g), _ptr(new[i]), self.stream())
-            self._fine_grid = new
+            self._fine_grid, self._fine_grid_key = new, key
         return self._fine_grid
 
     # ---- staging ---------------------------------------------------------------------------------------

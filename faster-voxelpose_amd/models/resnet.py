@@ -234,10 +234,11 @@ class PoseResNet(ParamTree):
         if dev.type == "cuda" and self.autotune and N not in plan["tuned"] and not torch.cuda.is_current_stream_capturing():
             # once per (image size, batch): time every conv with each tile configuration of the large-tile kernel
             # and keep the fastest (the configurations compute identical bits; ~100 ms, activation buffers as scratch)
-            ops = plan["tuned"][N] = (capi.FvpBbOp * len(plan["ops"]))(*plan["ops"])
+            ops = (capi.FvpBbOp * len(plan["ops"]))(*plan["ops"])
             rc = self.lib.fvp_bb_tune(ops, len(ops), C.c_void_p(self._wblob.data_ptr()), C.c_void_p(self._eblob.data_ptr()),
                                       arr, len(bufs), N, s)
             capi.check(self.lib, rc, "fvp_bb_tune")
+            plan["tuned"][N] = ops                       # recorded only once the tuner has succeeded
         ops_run = plan["tuned"].get(N, plan["ops"])
         rc = self.lib.fvp_bb_run(ops_run, len(plan["ops"]), C.c_void_p(self._wblob.data_ptr()),
                                  C.c_void_p(self._eblob.data_ptr()), arr, len(bufs), N,

@@ -184,7 +184,9 @@ int fvp_pack_conv(const float* weight, const float* bias, const float* bn_gamma,
 /* ---- a-6/a-7: NMS + top-k (bit-exact indices) -------------------------------------------------
  * hm2d [B][X][Y].  keep = (x == maxpool3x3(x)) ? x : 0 ; top-N by (value desc, flat index asc).
  * vals [B][N] fp32, idx [B][N][2] int64 = (flat / X, flat % X) -- the reference divides by
- * shape[1] = X (core/proposal.py:16-17), flat [B][N] int64.  Replaces core/proposal.py:13-33. */
+ * shape[1] = X (core/proposal.py:16-17), flat [B][N] int64.  Replaces core/proposal.py:13-33.
+ * One workgroup per frame with the map in LDS: FVP_ELIMIT when X * Y * 4 + 128 bytes exceed the CU's 160 KB
+ * (X * Y > 40 928, e.g. beyond 200 x 200); maps up to 128 x 128 take the register-resident fast path. */
 int fvp_nms_topk(const float* hm2d, int B, int X, int Y, int N, float* vals, int64_t* idx, int64_t* flat,
                  fvp_stream_t s);
 

@@ -81,6 +81,13 @@ def test_nms_topk_edge_cases(emu_lib):
     assert torch.equal(flat, of) and torch.equal(idx, oi) and torch.equal(vals, ov)
     assert flat[0, 0].item() == 0 and flat[0, 1].item() == 143
     assert flat[2].tolist() == [0, 1, 2, 3, 4, 5]
+    # more than 16 384 cells: keep bits + in-place LDS map instead of register-resident cells
+    big = torch.from_numpy(rng.normal(size=(2, 1, 136, 128)).astype(np.float32))
+    big[0, 0, 0, 0] = big[0, 0, 135, 127] = 9.0
+    big[1, 0, 70, 3] = big[1, 0, 70, 4] = 8.0
+    vals, idx, flat = nms2D(big, 5, _lib=emu_lib)
+    ov, oi, of = O.nms2d(big, 5)
+    assert torch.equal(flat, of) and torch.equal(idx, oi) and torch.equal(vals, ov)
 
 
 def test_conv_stack_matches_oracle_on_ragged_batch(emu_lib):

@@ -124,7 +124,8 @@ def test_empty_and_all_invalid():
 def test_nms_topk_exact_vs_oracle():
     from faster_voxelpose_amd.core.proposal import nms2D
     rng = np.random.default_rng(3)
-    for (B, X, Y, N) in ((5, 80, 80, 10), (2, 128, 128, 10), (3, 16, 16, 7)):
+    for (B, X, Y, N) in ((5, 80, 80, 10), (2, 128, 128, 10), (3, 16, 16, 7),
+                         (2, 200, 200, 10), (2, 150, 130, 12)):     # > 16 384 cells: the LDS-resident form
         m = torch.from_numpy(rng.normal(size=(B, 1, X, Y)).astype(np.float32))
         m[0, 0, 0, 0] = m[0, 0, X - 1, Y - 1] = 9.0      # tie -> lowest index first
         m[1, 0, 3, 3] = m[1, 0, 3, 4] = 8.0              # plateau

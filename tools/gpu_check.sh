@@ -15,7 +15,7 @@ echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 3 > "$out/bench
 # sweeps: batch size at the default pipeline depth (2 batches in flight), and pipeline depth at B = 8 / B = 1
 for spec in "1 3" "2 3" "16 3" "32 3" "8 1" "8 2" "1 1" "1 4"; do
   set -- $spec; b=$1; st=$2
-  timeout 600 python bench.py --steps 10 --warmup 3 --batch $b --streams $st --no-cpu-baseline > "$out/bench_${tag}_b${b}_s${st}.json" 2>> "$out/bench_${tag}.err"
+  timeout 600 python bench.py --steps 10 --warmup 3 --batch $b --streams $st --no-cpu-baseline --no-extra > "$out/bench_${tag}_b${b}_s${st}.json" 2>> "$out/bench_${tag}.err"
   python - "$out/bench_${tag}_b${b}_s${st}.json" <<'PY'
 import json, sys
 try:
@@ -26,8 +26,8 @@ PY
 done
 echo "== backbone (next row f-1)"
 timeout 600 python tools/bench_backbone.py --images 40 --iters 3 --per-op > "$out/backbone_per_op_${tag}.log" 2>&1; tail -2 "$out/backbone_per_op_${tag}.log"
-timeout 600 python bench.py --backbone --steps 8 --warmup 2 --streams 2 --no-cpu-baseline > "$out/bench_${tag}_e2e_b8_s2.json" 2>> "$out/bench_${tag}.err"
-timeout 600 python bench.py --backbone --steps 8 --warmup 2 --streams 1 --no-cpu-baseline > "$out/bench_${tag}_e2e_b8_s1.json" 2>> "$out/bench_${tag}.err"
+timeout 600 python bench.py --backbone --steps 8 --warmup 2 --streams 2 --no-cpu-baseline --no-extra > "$out/bench_${tag}_e2e_b8_s2.json" 2>> "$out/bench_${tag}.err"
+timeout 600 python bench.py --backbone --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --no-extra > "$out/bench_${tag}_e2e_b8_s1.json" 2>> "$out/bench_${tag}.err"
 python - "$out/bench_${tag}_e2e_b8_s2.json" "$out/bench_${tag}_e2e_b8_s1.json" <<'PY'
 import json, sys
 for f in sys.argv[1:]:
@@ -38,6 +38,6 @@ for f in sys.argv[1:]:
 PY
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-prof > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-prof --no-mpjpe --no-extra > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
 find "$out/prof_${tag}" -name "*kernel_stats*.csv" | head -1 | xargs -r head -40 | cut -c1-220
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_bb" -o trace -- python "$root/tools/bench_backbone.py" --images 40 --iters 3 > "$out/rocprof_${tag}_bb.log" 2>&1; echo "rocprof backbone rc=$?"

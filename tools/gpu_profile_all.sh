@@ -4,7 +4,7 @@
 # 1. GPU parity suite (parity report)      2. bench: default line + batch / pipeline-depth sweep + end-to-end
 # 3. rocprofv3 --kernel-trace --stats of the serial B=8 step and of the backbone
 # 4. PMC passes (SQ, GRBM, TCC, FETCH_SIZE, WRITE_SIZE: one group per pass) + summaries
-tag="${1:-r02}"; commit="${2:-?}"
+tag="${1:-r03}"; commit="${2:-?}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out"; dst="$out/profiles_${tag}"
 mkdir -p "$dst"
@@ -17,11 +17,11 @@ echo "== bench"
 timeout 600 python bench.py --steps 20 --warmup 3 > "$dst/${tag}_bench_b8.json" 2> "$out/bench_${tag}.err"; echo "bench rc=$?"
 for spec in "1 1" "1 3" "2 3" "8 1" "8 2" "16 3" "32 3"; do
   set -- $spec
-  timeout 300 python bench.py --steps 10 --warmup 3 --batch $1 --streams $2 --no-cpu-baseline > "$dst/${tag}_bench_b$1_s$2.json" 2>> "$out/bench_${tag}.err"
+  timeout 300 python bench.py --steps 10 --warmup 3 --batch $1 --streams $2 --no-cpu-baseline --no-extra > "$dst/${tag}_bench_b$1_s$2.json" 2>> "$out/bench_${tag}.err"
 done
 timeout 300 python tools/bench_backbone.py --images 40 --iters 3 --per-op > "$dst/${tag}_backbone_per_op.log" 2>&1
 for st in 1 2 3; do
-  timeout 300 python bench.py --backbone --steps 8 --warmup 2 --streams $st --no-cpu-baseline > "$dst/${tag}_bench_e2e_b8_s$st.json" 2>> "$out/bench_${tag}.err"
+  timeout 300 python bench.py --backbone --steps 8 --warmup 2 --streams $st --no-cpu-baseline --no-extra > "$dst/${tag}_bench_e2e_b8_s$st.json" 2>> "$out/bench_${tag}.err"
 done
 timeout 300 python tools/bench_conv.py --net conv_net --frames 8 --iters 10 > "$dst/${tag}_conv_per_op_p2pnet_b8.log" 2>&1
 timeout 300 python tools/bench_conv.py --net center_net --frames 8 --iters 10 > "$dst/${tag}_conv_per_op_centernet_b8.log" 2>&1
@@ -36,7 +36,7 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json
 PY
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-prof > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-prof --no-mpjpe --no-extra > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
 find "$out/prof_${tag}" -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} "$dst/${tag}_kernel_stats_b8.csv"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_bb" -o trace -- python "$root/tools/bench_backbone.py" --images 40 --iters 3 > "$out/rocprof_${tag}_bb.log" 2>&1
 find "$out/prof_${tag}_bb" -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} "$dst/${tag}_kernel_stats_backbone.csv"

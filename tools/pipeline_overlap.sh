@@ -4,7 +4,7 @@
 streams="${1:-3}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"; out="$root/gpurun_out/overlap"; rm -rf "$out"; mkdir -p "$out"
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$out" -o t -- python "$root/bench.py" --steps 40 --warmup 5 --streams "$streams" --no-cpu-baseline --no-prof > "$out/bench.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$out" -o t -- python "$root/bench.py" --steps 40 --warmup 5 --streams "$streams" --no-cpu-baseline --no-prof --no-mpjpe --no-extra > "$out/bench.log" 2>&1
 f=$(find "$out" -name "*kernel_trace.csv" | head -1)
 python3 - "$f" "$streams" <<'PY'
 import csv, sys

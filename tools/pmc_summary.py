@@ -36,31 +36,43 @@ for n in rows:
         print(f"   HBM-side traffic per launch: fetch {f / 1024:.2f} MiB (x2 correction: {2 * f / 1024:.2f} MiB), "
               f"write {w / 1024:.2f} MiB")
 
-# machine-readable traffic summary for bench.py's roofline.traffic
-import json
-out = {}
-grp = {"conv_wino": [0.0, 0.0, 0.0], "conv_dma": [0.0, 0.0, 0.0]}
-for n in rows:
-    c = {k: sum(v) / len(v) for k, v in acc[n].items()}
-    nl = len(acc[n].get("FETCH_SIZE", []))
-    g = "conv_wino" if "k_conv_wino" in n else ("conv_dma" if "k_conv" in n else None)
-    if g and nl:
-        grp[g][0] += c.get("FETCH_SIZE", 0.0) * nl
-        grp[g][1] += c.get("WRITE_SIZE", 0.0) * len(acc[n].get("WRITE_SIZE", []))
-        grp[g][2] += nl
-    if "k_project_triplane" in n and nl:
-        out["project_triplane_bytes_per_launch"] = (2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024
-    if "k_project_whole" in n and nl:
-        out["project_whole_bytes_per_launch"] = (2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024
-for g, (f, w, n) in grp.items():
-    if n:
-        out[g + "_bytes_per_launch"] = (2 * f + w) * 1024 / n
-        out[g + "_launches_sampled"] = n
-out["note"] = "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)"
+# machine-readable traffic summary for bench.py's roofline.traffic: one entry per kernel CLASS, averaged over the
+# launches of every template variant seen (all of them listed, none silently dropped).  The profiled command runs the
+# B = 8 step only (bench.py --no-mpjpe --no-extra): no fixture-sized launches enter the averages (round 2's file mixed
+# them in, and kept only the last-seen variant for the projection kernels).
 import datetime
+import json
+
+CLASSES = {"k_conv_wino": lambda n: "k_conv_wino" in n,
+           "k_conv_dma": lambda n: "k_conv" in n and "k_conv_wino" not in n and "k_conv1d" not in n,
+           "k_conv1d_fused": lambda n: "k_conv1d" in n,
+           "k_project_triplane": lambda n: "k_project_triplane" in n,
+           "k_project_whole": lambda n: "k_project_whole" in n}
+out = {"workload": {"config": os.environ.get("FVP_PMC_CONFIG", "panoptic"),
+                    "frames_per_step": int(os.environ.get("FVP_PMC_BATCH", "8"))},
+       "classes": {}}
+for cls, match in CLASSES.items():
+    variants, tot_b, tot_n = {}, 0.0, 0
+    for n in rows:
+        if not match(n):
+            continue
+        fs, ws = acc[n].get("FETCH_SIZE", []), acc[n].get("WRITE_SIZE", [])
+        if not fs or not ws:
+            continue
+        f, w = sum(fs) / len(fs), sum(ws) / len(ws)
+        b = (2 * f + w) * 1024
+        variants[n] = {"bytes_per_launch": b, "fetch_KiB_raw": f, "write_KiB": w, "launches": len(fs),
+                       "mean_us": sum(dur[n]) / len(dur[n])}
+        tot_b += b * len(fs)
+        tot_n += len(fs)
+    if tot_n:
+        out["classes"][cls] = {"bytes_per_launch": tot_b / tot_n, "launches": tot_n, "variants": variants}
+out["note"] = ("bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts "
+               "128-B requests as 64 B); per class = launch-weighted mean over the listed variants")
 out["collected"] = datetime.date.today().isoformat()
 out["commit"] = sys.argv[3] if len(sys.argv) > 3 else "?"
-out["how"] = "tools/gpu_profile_all.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 3 --streams 1"
+out["how"] = ("tools/gpu_pmc.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+              "`bench.py --steps 3 --streams 1 --no-mpjpe --no-extra --no-cpu-baseline --no-prof`")
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     print("wrote", sys.argv[2])
