@@ -567,7 +567,14 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&a
 // cb + CB/2 of a lane are output pixels (2x, 2x+1) of the same cout: the input tile is read once
 // for both taps and the outputs leave as float2 (the tap-per-launch form reads it four times and
 // stores single floats at stride 2).
-template <int KH, int KW, int CB, int PB, bool PAIR = false, bool TPAIR = false>
+//
+// KS (split K; small maps with long reductions: CenterNet's 3x3 layers on the 20x20 / 40x40 levels, 64-128
+// channels): with a handful of planes such a layer has fewer pixel blocks than the chip has SIMDs, and a wave's
+// output is ONE dependent chain of cinp*9/2 = 288-576 MFMAs (64 cycles each: 8-15 us before the first store).
+// Here the four waves of a workgroup share one pixel block and each takes every fourth channel pair of a chunk;
+// the four partial tiles are added in the fixed order ((w0 + w1) + w2) + w3 through LDS and wave 0 runs the
+// epilogue.  Chosen from the layer SHAPE only, so a frame's result does not depend on its batch.
+template <int KH, int KW, int CB, int PB, bool PAIR = false, bool TPAIR = false, bool KS = false>
 __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_conv_dma(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
   constexpr int KT = PAIR ? KW + 1 : KW;             // taps per kernel row in the packed layout
@@ -594,9 +601,10 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
   const int Wq = PAIR ? W >> 1 : W;                  // tile columns per image row (pixels or pixel pairs)
   const int tile_px = a.TN * a.TH * Wq;
   int poff[PB];
+  const int pwave = KS ? 0 : wave;                   // KS: every wave works on the workgroup's first PB pixel blocks
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
-    const int q = (wave * PB + pb) * 32 + l31;
+    const int q = (pwave * PB + pb) * 32 + l31;
     const int qc = q < tile_px ? q : 0;
     const int n = fdiv(qc, a.m_thw), r = qc - n * (a.TH * Wq);
     const int ty = fdiv(r, a.m_w), tx = r - ty * Wq;
@@ -683,6 +691,8 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
     // compiler pair neighbouring taps into ds_read2_b32 (B: adjacent floats; A: CBW apart) and needs
     // one address add per (row, pixel block) instead of one per tap.
     float av[2][KT][CB], bv[2][KT][PB];
+    constexpr int CSTEP = KS ? 8 : 2;                // channel distance between a wave's consecutive channel pairs
+    const int cfirst = KS ? 2 * wave : 0;            // (host: CC % 8 == 0 for KS)
     auto fetch = [&](int set, int ci, int ky, int wp) {
       const int cic = ci < a.CC ? ci : a.CC - 2;              // last prefetch of a chunk: harmless re-read
       const float* xs = Xs + (cic + half) * CS + ky * wp;
@@ -707,7 +717,7 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
         __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0), vmcnt/expcnt untouched
         __builtin_amdgcn_sched_barrier(0);
         if (ky + 1 < KH) fetch(nxt, ci, ky + 1, wp);
-        else fetch(nxt, ci + 2, 0, wp);
+        else fetch(nxt, ci + CSTEP, 0, wp);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < KT; ++kx)
@@ -720,15 +730,42 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
       }
     };
     if (!(a.ablate & 4)) {
-      fetch(0, 0, 0, WP);
-      for (int ci = 0; ci < a.CC; ci += 4) {
+      fetch(0, cfirst, 0, WP);
+      for (int ci = cfirst; ci < a.CC; ci += 2 * CSTEP) {
         block(std::integral_constant<int, 0>{}, ci);
-        if (ci + 2 < a.CC) block(std::integral_constant<int, 1>{}, ci + 2);
+        if (ci + CSTEP < a.CC) block(std::integral_constant<int, 1>{}, ci + CSTEP);
       }
     }
     __syncthreads();
   }
   if (a.ablate & 8) return;
+  if constexpr (KS) {
+    // the chunk loop ended with a barrier: the slots are free.  red[w - 1][cb][pb][r][lane]
+    float* red = smem + 4;
+    if (wave > 0) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((((wave - 1) * CB + cb) * PB + pb) * 16 + r) * 64 + lane] = acc[cb][pb][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[cb][pb][r] += red[((((w - 1) * CB + cb) * PB + pb) * 16 + r) * 64 + lane];
+    if (a.flags & FVP_EPI_RES)
+      conv_epilogue<CB, PB, true>(a, acc, 0, l31, half, plane0, y0, 0, co0, tapT);
+    else
+      conv_epilogue<CB, PB, false>(a, acc, 0, l31, half, plane0, y0, 0, co0, tapT);
+    return;
+  }
   if (PAIR) {
     if (a.flags & FVP_EPI_RES)
       conv_epilogue_pair<PB, true>(a, acc[0], wave, l31, half, plane0, y0);
@@ -903,6 +940,7 @@ static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
 static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const int kNoHeadFuse = int(env_size("FVP_CONV_NO_HEAD_FUSE", 0));
+static const int kNoKSplit = int(env_size("FVP_CONV_NO_KSPLIT", 0));   // diagnostics: no split-K form for the small-map 3x3 layers
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
 static const int kWinoGeneric = int(env_size("FVP_WINO_GENERIC", 0));
 static const int kWinoWC1 = int(env_size("FVP_WINO_WC1", 0));        // diagnostics: 32-cout blocks for every layer
@@ -1146,8 +1184,20 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
     while (PB > 1 && (px_total + 128 * PB - 1) / (128 * PB) * CBfull < 512) PB >>= 1;
   }
   if (kForcePB && CB * kForcePB <= 4) PB = kForcePB;
+  // split K over the four waves (k_conv_dma<..., KS>): 3x3 layers with >= 64 channels on maps of 256 .. 576 pixels
+  // (CenterNet's 20x20 level: reductions of 576-1152 terms, 13-52 pixel blocks per plane).  Measured on the MI355X:
+  // 128->128 @20x20 32.3 -> 18.7 us at one plane (33.3 -> 31.0 at eight); the 40x40 level gains nothing at one plane
+  // (18.9 -> 18.2 us) and doubles at eight planes (every workgroup stages the same weight slice), so it stays on the
+  // plain form.  A SHAPE rule (map size, channels), never the number of planes: a frame's result does not depend on
+  // the batch it is computed in.
+  const bool ksplit = !tr && !pair && !kNoKSplit && kh == 3 && kw == 3 && op.w % 4 == 0 && op.w <= 32 && op.h * op.w >= 256 &&
+                      op.h * op.w <= 576 && op.cinp >= 64 && op.cinp % 8 == 0 && !kNoDma;
+  if (ksplit) {
+    CB = 1;
+    PB = 1;                                               // one image row (plus masked lanes) per workgroup
+  }
   a.ablate = kAblate;
-  const int TP = PB * 128;
+  const int TP = ksplit ? PB * 32 : PB * 128;
   if (hw <= TP) {                       // whole planes per tile
     a.TW = op.w;
     a.TH = op.h;
@@ -1181,6 +1231,11 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
     while (CC > 2 && size_t(CC) * a.TN * (a.TH + kh - 1) * (a.TW / 4 + 1) + 1 > 2048) CC -= 2;
   for (int d = CC; d >= 2 && d * 2 > CC; d -= 2)      // avoid a ragged last chunk when a close divisor exists
     if (op.cinp % d == 0) { CC = d; break; }
+  if (ksplit) {                                       // whole groups of four channel pairs; no ragged chunk
+    if (!a.dma || CC < 8) return FVP_ELIMIT;
+    CC &= ~7;
+    while (CC > 8 && op.cinp % CC) CC -= 8;
+  }
   a.CC = CC;
   a.m_qpr = make_magic(a.dma ? a.TW / 4 + 1 : a.TW / 4);
   a.m_rpc = make_magic(a.TN * (a.TH + kh - 1));
@@ -1192,6 +1247,11 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   // algorithmic FLOPs (2*MAC on the true channel counts)
   const double taps = tr ? double(a.ntapT) : double(op.kh * op.kw);
   ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * op.h * op.w * planes, 1, prof_level() >= 2);
+  if (ksplit) {
+    const size_t lds_ks = std::max<size_t>(lds, 16 + size_t(3) * PB * 16 * 64 * sizeof(float));
+    hipLaunchKernelGGL((k_conv_dma<3, 3, 1, 1, false, false, true>), grid, dim3(256), lds_ks, s, a);
+    return launch_status();
+  }
   if (pair) {
     if (!a.dma || CB != 1 || kh != 7 || kw != 7) return FVP_ELIMIT;
     a.wts = params + op.pair_off;

@@ -111,3 +111,50 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
     pl = planes.detach().cpu().numpy()
     tol = BAR_MM if is_conditioned(case) else max(BAR_MM, FLOOR_FACTOR * floor) * 2
     np.testing.assert_allclose(pl, g["plane_poses"], rtol=0, atol=tol)
+
+
+def run_custom_conv_stack(lib, device, spec, weights, x, stream=None):
+    """Run a hand-made ``netspec.StackSpec`` (finalized) through fvp_pack_conv + fvp_conv_stack_run.
+    ``weights``: {key + '.weight' / '.bias': tensor}; ``x``: [planes, C, H, W].  Returns every activation buffer."""
+    import ctypes as C
+
+    from faster_voxelpose_amd import _capi as capi
+    blob = torch.zeros(max(spec.nparams, 4), device=device)
+    s = stream
+    for key, bn, transposed, oi in spec.param_keys:
+        assert bn is None
+        w = weights[key + ".weight"].to(device).contiguous()
+        b = weights[key + ".bias"].to(device).contiguous()
+        capi.check(lib, lib.fvp_pack_conv(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None, 1e-5,
+                                          1 if transposed else 0, C.byref(spec.op_array[oi]), C.c_void_p(blob.data_ptr()), s),
+                   "fvp_pack_conv")
+    planes = x.shape[0]
+    bufs = [x.to(device).contiguous()] + [torch.empty((planes,) + tuple(b), device=device) for b in spec.bufs[1:]]
+    arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+    capi.check(lib, lib.fvp_conv_stack_run(spec.op_array, len(spec.ops), C.c_void_p(blob.data_ptr()), arr, len(bufs), planes,
+                                           None, 1, s), "fvp_conv_stack_run")
+    return bufs
+
+
+def split_k_stack(cin, cmid, hw, seed=0):
+    """conv3x3 cin->cmid (ReLU) then conv3x3 cmid->cmid + residual (ReLU) on a map that is NOT a power of two
+    (so the direct kernel runs, and with >= 64 channels on <= 40x40 its split-K form): spec, weights, torch reference."""
+    import torch.nn.functional as F
+
+    from faster_voxelpose_amd import netspec
+    spec = netspec.StackSpec(2, cin, hw)
+    spec._conv_entries("a", cin, cmid, 3)
+    spec._conv_entries("b", cmid, cmid, 3)
+    h = spec.conv("a", None, 0, cmid, 3, relu=True)
+    o = spec.conv("b", None, h, cmid, 3, relu=True, res=h)
+    spec.outputs["out"] = o
+    spec.finalize()
+    g = torch.Generator().manual_seed(seed)
+    w = {"a.weight": torch.randn(cmid, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, "a.bias": torch.randn(cmid, generator=g) * 0.1,
+         "b.weight": torch.randn(cmid, cmid, 3, 3, generator=g) / (cmid * 9) ** 0.5, "b.bias": torch.randn(cmid, generator=g) * 0.1}
+
+    def ref(x):
+        x = x.double()
+        h1 = F.relu(F.conv2d(x, w["a.weight"].double(), w["a.bias"].double(), padding=1))
+        return F.relu(F.conv2d(h1, w["b.weight"].double(), w["b.bias"].double(), padding=1) + h1)
+    return spec, w, ref, o

@@ -13,7 +13,7 @@ import torch
 
 import fvp_oracle as O
 from cases import make_inputs, make_weights
-from common import check_outputs, load_golden
+from common import check_outputs, load_golden, run_custom_conv_stack, split_k_stack
 import fvp_synthetic as S
 from faster_voxelpose_amd.models import faster_voxelpose as FV
 
@@ -235,3 +235,15 @@ def test_winograd_on_maps_that_do_not_divide_the_workgroup_tile(emu_lib, monkeyp
         hm, sz = model.pose_net.center_net(cubes)
     np.testing.assert_allclose(hm.numpy(), hm_w.numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(sz.numpy(), sz_w.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,cmid,hw,planes", [(64, 128, (16, 20), 3), (128, 64, (24, 24), 2)])
+def test_split_k_direct_conv_on_small_maps(emu_lib, cin, cmid, hw, planes):
+    """k_conv_dma<..., KS>: 3x3 layers with >= 64 channels on small non-power-of-two maps split the reduction over the
+    four waves of a workgroup (CenterNet's 20x20 / 40x40 levels).  Against a float64 torch evaluation, ragged plane
+    count, residual + ReLU epilogue; maps of 256 .. 576 pixels take the split form (rows of 20 and 24: masked lanes)."""
+    spec, w, ref, o = split_k_stack(cin, cmid, hw, seed=cin)
+    x = torch.from_numpy(np.random.default_rng(5).normal(size=(planes, cin) + hw).astype(np.float32))
+    got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)[o]
+    want = ref(x)
+    np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)

@@ -10,7 +10,7 @@ import torch
 
 import fvp_oracle as O
 from cases import CASES, make_inputs, make_weights
-from common import check_outputs, load_golden
+from common import check_outputs, load_golden, run_custom_conv_stack, split_k_stack
 import fvp_synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -44,6 +44,32 @@ def test_golden_case(case):
         with open(REPORT, "a") as f:
             f.write(json.dumps(report) + "\n")
         print(report)
+
+
+@pytest.mark.parametrize("name", ["panoptic_b8", "shelf_b2", "panoptic128_b1", "campus_b2"])
+def test_float_parity_seed_sweep(name):
+    """North-star float bar WITHOUT hand-picked seeds: 10 consecutive heatmap seeds per shape through the reference
+    (tests/golden/make_seed_sweep.py), MIN_SCORE fixed at 0.4, Panoptic at the benchmark's own batch (B = 8), jln128
+    and Campus included.  Rules R1 / R1p / R2 and their history in tests/golden/seed_sweep.py:
+      R1  joints whose own reference fp32-vs-fp64 floor is <= 4e-4 mm: |build - ref32| <= 1e-3 mm - asserted with zero
+          exceptions for panoptic_b8 and panoptic128_b1, reported for Shelf / Campus;
+      R1p joints of proposals whose worst-joint floor is <= 4e-4 mm: <= 1e-3 mm, every shape;
+      R2  every joint: |build - ref32| <= 3 x max(its proposal's floor, 4e-4) - never noisier than the reference;
+      proposal centres bit-equal; the overall fraction within 1e-3 mm goes to the parity report."""
+    import seed_sweep as SW
+    s, rows = SW.replay(name, DEV, detail_path=os.path.join(os.path.dirname(REPORT), f"sweep_detail_{name}.npy"))
+    rep = dict(s, case="sweep_" + name, rows=rows)
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(rep) + "\n")
+    print(rep)
+    assert s["seeds"] == SW.SEEDS and s["joints"] > 300
+    assert s["centres_exact"], "proposal centres / valid flags differ from the reference"
+    if name in ("panoptic_b8", "panoptic128_b1"):
+        assert s["violations_where_floor_le_4e-4"] == 0, s                       # R1
+    assert s["violations_in_proposals_with_floor_le_4e-4"] == 0, s               # R1p
+    assert name == "campus_b2" or s["joints_of_proposals_with_floor_le_4e-4"] > 300
+    assert s["worst_err_over_proposal_floor"] <= 3.0, s                          # R2
 
 
 def test_fused_projection_equals_materialised_full_size():
@@ -132,6 +158,24 @@ def test_nms_topk_exact_vs_oracle():
         vals, idx, flat = nms2D(m.to(DEV), N)
         ov, oi, of = O.nms2d(m, N)
         assert torch.equal(flat.cpu(), of) and torch.equal(idx.cpu(), oi) and torch.equal(vals.cpu(), ov)
+
+
+@pytest.mark.parametrize("cin,cmid,hw,planes", [(64, 128, (20, 20), 1), (128, 128, (20, 20), 8), (64, 64, (24, 20), 3),
+                                                 (128, 64, (40, 40), 2)])
+def test_split_k_direct_conv_on_small_maps(cin, cmid, hw, planes):
+    """CenterNet's 3x3 layers on the 20x20 level (maps of 256 .. 576 pixels, >= 64 channels) run the split-K form of the
+    direct kernel (four waves share a pixel block, fixed-order reduction); 40x40 stays on the plain form.  Against a
+    float64 torch evaluation, and bit-identical for a plane whatever the number of planes in the launch (the form is
+    chosen from the layer shape, never from the batch)."""
+    from faster_voxelpose_amd import _capi as capi
+    lib = capi.load()
+    spec, w, ref, o = split_k_stack(cin, cmid, hw, seed=cin)
+    x = torch.from_numpy(np.random.default_rng(5).normal(size=(planes, cin) + hw).astype(np.float32))
+    st = torch.cuda.current_stream().cuda_stream
+    got = run_custom_conv_stack(lib, DEV, spec, w, x, st)[o].cpu()
+    np.testing.assert_allclose(got.double().numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5)
+    one = run_custom_conv_stack(lib, DEV, spec, w, x[planes - 1:], st)[o].cpu()
+    assert torch.equal(one[0], got[planes - 1])
 
 
 def test_conv_stacks_vs_torch_fp32():
