@@ -17,9 +17,14 @@
 // DMA is fully hidden), without the MFMA loop 134, skeleton alone (DMA + rendezvous) 41; requesting the operands
 // of the next channel pair before the MFMAs of the current one changes nothing (236): what is left is the 25
 // dependent op steps (K-slice reduction + epilogue, ~4 us each) and the 32-wide MFMA on 5-20 useful columns.
+// Round 3: (i) the operand words of up to four channel pairs are fetched as one batch in front of their MFMAs (the
+// per-MFMA LDS latency was most of the "MFMA loop" above); (ii) the K-slice reduction
+// and the epilogue are spread over all sixteen waves (slice ks finishes 4 of the 16 accumulator registers of its cout
+// block) instead of four finishers doing all the work while twelve waves wait.
 // Deterministic; differs from the generic interpreter's single k-ordered chain only in rounding.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "fvp_common.h"
@@ -48,26 +53,50 @@ struct Fused1dArgs {
   int buf_off[kMaxBufs];     // LDS float offset of each activation buffer
   int buf_w[kMaxBufs];       // slot width (floats) of each buffer
   int nops, nchunks, planes, cin, L, lds_floats;
+  int ablate;                // diagnostics (FVP_C1D_ABLATE): 1 no MFMA loop, 2 no reduction / epilogue, 4 no DMA wait, 8 no DMA (wrong results)
   const float* params;
   const float* in;           // [planes][cin][L]
   float* out;                // [planes][cout_last][L_last]
 };
 
+// MFMAs of one weight chunk for wave (cb, ks): channel pairs ks, ks + kKS, ... in batches of two pairs (k7: one).  All
+// operand words of a batch (6-7 A-words and B-words) are requested before its first MFMA, so a chunk costs one
+// LDS latency instead of one per MFMA (a wave has only 12-14 MFMAs per chunk: the fetch latency was most of the loop).
+// Same k order per slice as before: results are unchanged.
 template <int KW>
 __device__ __forceinline__ void conv_chunk(const Fused1dArgs& a, const FvpConvOp& op, const Chunk& ch,
-                                           const float* lds, const float* wbuf, f32x16& acc, int lane, int cb, int ks) {
+                                           const float* lds, const float* wbuf, f32x16& acc0, int lane, int cb, int ks) {
   const int half = lane >> 5, l31 = lane & 31;
   constexpr int pad = (KW - 1) / 2;
   const int sw = a.buf_w[op.src];
   const float* in = lds + a.buf_off[op.src] + l31 - pad + (2 * (ch.row0 / (2 * KW)) + half) * sw;
   const float* ws = wbuf + cb * 32 + l31 + half * KW * op.coutp;
   const int np = ch.nrows / (2 * KW);
-  for (int p = ks; p < np; p += kKS) {
+  constexpr int NB = KW >= 7 ? 1 : 2;                  // pairs per batch: 12-14 operand registers (16 waves: 128 VGPRs, no spills)
+  for (int p0 = ks; p0 < np; p0 += NB * kKS) {
+    float av[NB][KW], bv[NB][KW];
 #pragma unroll
-    for (int t = 0; t < KW; ++t) {
-      const float av = ws[(2 * p * KW + t) * op.coutp];
-      const float bv = in[2 * p * sw + t];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    for (int u = 0; u < NB; ++u) {
+      const int p = p0 + u * kKS;
+      if (p < np) {                                    // wave-uniform
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+          av[u][t] = ws[(2 * p * KW + t) * op.coutp];
+          bv[u][t] = in[2 * p * sw + t];
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the whole batch has landed
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int p = p0 + u * kKS;
+      if (p < np) {
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u][t], acc0, 0, 0, 0);
+        }
+      }
     }
   }
 }
@@ -83,7 +112,7 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
 
   // LDS-DMA of chunk c's weight rows into ring slot c % kNB; returns this wave's instruction count
   auto stage = [&](int c) -> int {
-    if (c >= a.nchunks) return 0;
+    if (c >= a.nchunks || (a.ablate & 8)) return 0;
     const Chunk& ch = a.chunks[c];
     if (ch.nrows == 0) return 0;
     const FvpConvOp& op = a.ops[ch.op];
@@ -133,9 +162,9 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
   }
   __syncthreads();
 
-  f32x16 acc;
+  f32x16 acc0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
   for (int c = 0; c < a.nchunks; ++c) {
     // ring slot (c + kNB - 1) % kNB was last read during chunk c - 1, which every wave has left
     if (c > 0) {
@@ -149,7 +178,7 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
 #pragma unroll
       for (int k = 1; k < kNB - 1; ++k) keep += ninfl[k];
       __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0)
-      wait_vmcnt(keep);
+      if (!(a.ablate & 4)) wait_vmcnt(keep);
       __builtin_amdgcn_s_barrier();
     };
     const Chunk& ch = a.chunks[c];
@@ -178,31 +207,49 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
     const int ncb = op.coutp / 32;
     const bool active = wave < ncb;
     float* const wcur = wbufs + (c % kNB) * kWFloats;
-    if (active) {
+    if (active && !(a.ablate & 1)) {
       if (ch.first) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
       }
-      if (tr || op.kw == 1) conv_chunk<1>(a, op, ch, lds, wcur, acc, lane, wave, ks);
-      else if (op.kw == 3) conv_chunk<3>(a, op, ch, lds, wcur, acc, lane, wave, ks);
-      else conv_chunk<7>(a, op, ch, lds, wcur, acc, lane, wave, ks);
+      if (tr || op.kw == 1) conv_chunk<1>(a, op, ch, lds, wcur, acc0, lane, wave, ks);
+      else if (op.kw == 3) conv_chunk<3>(a, op, ch, lds, wcur, acc0, lane, wave, ks);
+      else conv_chunk<7>(a, op, ch, lds, wcur, acc0, lane, wave, ks);
     }
-    if (ch.last) {
-      // ---- K-slice reduction through the ring slot this chunk just consumed (free until the next iteration's
-      //      DMA): slices 1.. write, slice 0 adds them in order.  [ks-1][cb][r][lane]
+    if (ch.last && !(a.ablate & 2)) {
+      // ---- K-slice reduction + epilogue, spread over ALL waves of a cout block: slice ks finishes accumulator
+      //      registers 4 ks .. 4 ks + 3 (couts cb * 32 + 8 ks + 4 half + 0..3).  Every slice parks the 12 registers it
+      //      does not finish in the ring slot this chunk just consumed (free until the next iteration's DMA):
+      //      part[cb][slice][12][lane]; the owner then adds the four slices in the fixed order 0, 1, 2, 3 (its own
+      //      from registers) - the order the single-finisher form used, so results are unchanged by the spreading.
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_s_barrier();                    // every wave is done reading the slot's weights
-      if (active && ks > 0) {
+      f32x16& acc = acc0;
+      if (active) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wcur[(((ks - 1) * 4 + wave) * 16 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; ++r)
+          if ((r >> 2) != ks) wcur[((wave * kKS + ks) * 12 + (r < 4 * ks ? r : r - 4)) * 64 + lane] = acc[r];
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_s_barrier();
-      if (active && ks == 0) {
+      if (active) {
+        float own[4];
 #pragma unroll
-        for (int k2 = 1; k2 < kKS; ++k2)
+        for (int i = 0; i < 4; ++i) {                  // wave-uniform selects: no dynamic register indexing
+          own[i] = ks == 0 ? acc[i] : (ks == 1 ? acc[4 + i] : (ks == 2 ? acc[8 + i] : acc[12 + i]));
+        }
+        float v4[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] += wcur[(((k2 - 1) * 4 + wave) * 16 + r) * 64 + lane];
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * ks + i;
+          float v = 0.0f;
+#pragma unroll
+          for (int k2 = 0; k2 < kKS; ++k2) {
+            const float x = k2 == ks ? own[i] : wcur[((wave * kKS + k2) * 12 + (r < 4 * k2 ? r : r - 4)) * 64 + lane];
+            v = k2 == 0 ? x : v + x;
+          }
+          v4[i] = v;
+        }
         // ---- epilogue: slot column j = l31; data columns [4, 4 + Lin)
         const int Lo = tr ? 2 * Lin : Lin;
         const int dw = a.buf_w[op.dst];
@@ -218,15 +265,24 @@ __global__ void __launch_bounds__(kNT1) k_conv1d_fused(Fused1dArgs a) {
         const int x = l31 - 4;
         const bool data = x >= 0 && x < Lin;
         const int oc = tr ? 4 + 2 * x + ch.tap : l31;  // output slot column
+        const int co0 = wave * 32 + 8 * ks + 4 * half; // this lane's four consecutive couts
+        float b4[4], s4[4], h4[4], r4[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int i = 0; i < 4; ++i) {                  // all LDS operands first (epi vectors are padded to coutp)
+          b4[i] = bias[co0 + i];
+          s4[i] = scale[co0 + i];
+          h4[i] = shift[co0 + i];
+          r4[i] = (has_res && data && co0 + i < op.cout) ? res[(co0 + i) * rw + oc] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = co0 + i;
           if (co < op.cout) {
-            float v = bn_affine(acc[r], bias[co], scale[co], shift[co]);
+            float v = bn_affine(v4[i], b4[i], s4[i], h4[i]);
             if (data) {
-              if (has_res && !res_after) v += res[co * rw + oc];
+              if (has_res && !res_after) v += r4[i];
               if (relu) v = fmaxf(v, 0.0f);
-              if (has_res && res_after) v += res[co * rw + oc];
+              if (has_res && res_after) v += r4[i];
             } else {
               v = 0.0f;
             }
@@ -341,6 +397,8 @@ extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const
   a.L = ops[0].w;
   total = (total + 64 + 3) & ~3;                     // slack for channel-padding rows; keeps the weight buffers 16-B aligned
   a.lds_floats = total;
+  static const int kAblate1d = getenv("FVP_C1D_ABLATE") ? atoi(getenv("FVP_C1D_ABLATE")) : 0;
+  a.ablate = kAblate1d;
   a.params = params;
   a.in = in;
   a.out = out;
@@ -349,7 +407,7 @@ extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const
   static LdsOptIn optin;
   if (lds_opt_in(optin, reinterpret_cast<const void*>(&k_conv1d_fused), lds > 64 * 1024 ? 160 * 1024 : 0)) return FVP_ELIMIT;
   ProfScope ps(FVP_K_CONV, as_stream(s), flops, nops, prof_level() >= 1);
-  static_assert((kKS - 1) * 4 * 16 * 64 <= kWFloats, "the K-slice partials must fit one ring slot");
+  static_assert(kKS * 4 * 12 * 64 <= kWFloats, "the K-slice partials must fit one ring slot");
   hipLaunchKernelGGL(k_conv1d_fused, dim3(planes), dim3(kNT1), lds, as_stream(s), a);
   return launch_status();
 }
