@@ -552,6 +552,86 @@ def test_backbone_tile_configurations_are_bit_identical_per_op():
 
 # ---- edge cases shared with the emulator suite (tests/edge_cases.py) ---------------------------------
 @pytest.mark.gpu
+def test_backbone_single_layers_vs_bf16_oracle():
+    """Per-layer parity of the bf16 backbone kernels on the GPU (layers were only compared on
+    the emulator): the first conv of every stage, every stride-2 3x3, every downsample, a residual expansion per stage
+    and all three transposed convs of the Pose-ResNet-50 plan, each run ALONE through fvp_bb_run on random bf16
+    activations and compared with the oracle's numerics for that layer (bf16 inputs / weights, fp32 accumulation, eval
+    BatchNorm as scale / shift, residual, ReLU, one rounding to bf16).  The two differ only in the fp32 summation
+    order in front of the bf16 rounding: every element within one bf16 ulp (2e-6 absolute where a layer's terms cancel),
+    all but a few per cent bit-equal."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from faster_voxelpose_amd import _capi as capi
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    m = RN.get(CFG.default_config()).to("cuda:0")
+    sd = S.fill_backbone_state_dict(m.state_dict(), seed=11)
+    m.load_state_dict(sd)
+    m.autotune = False
+    N, H, W = 2, 128, 160
+    with torch.no_grad():
+        m(torch.rand(N, 3, H, W, device="cuda"))                       # packs the weights
+    plan = m._plan(H, W)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    bufs = []
+    for name in plan["names"]:
+        c, h, w = plan["shapes"][name]
+        bufs.append((torch.rand((N, h, w, c), device="cuda", generator=g) - 0.5).bfloat16())
+    arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    want = set()
+    for li in (1, 2, 3, 4):
+        want |= {f"layer{li}.0.conv1", f"layer{li}.0.conv2", f"layer{li}.0.downsample.0", f"layer{li}.0.conv3", f"layer{li}.1.conv3"}
+    want |= {"deconv_layers.0", "deconv_layers.3", "deconv_layers.6"}
+    checked, worst_frac = 0, 0.0
+    for i, o in enumerate(m._convs):
+        if o.get("key") not in want:
+            continue
+        op = plan["ops"][i]
+        one = (capi.FvpBbOp * 1)(op)
+        bufs[op.dst].zero_()
+        capi.check(m.lib, m.lib.fvp_bb_run(one, 1, C.c_void_p(m._wblob.data_ptr()), C.c_void_p(m._eblob.data_ptr()), arr,
+                                           len(bufs), N, None, 0, None, st), "fvp_bb_run")
+        torch.cuda.synchronize()
+        got = bufs[op.dst].float().cpu()                                           # NHWC
+        x = bufs[op.src].float().cpu().permute(0, 3, 1, 2)
+        wq = sd[o["key"] + ".weight"].bfloat16().float()
+        if op.kind == capi.BB_DECONV:
+            y = F.conv_transpose2d(x, wq, None, stride=2, padding=1)
+        else:
+            y = F.conv2d(x, wq, None, stride=o["stride"], padding=o["pad"])
+        sc = sd[o["bn"] + ".weight"] / torch.sqrt(sd[o["bn"] + ".running_var"] + 1e-5)
+        sh = sd[o["bn"] + ".bias"] - sd[o["bn"] + ".running_mean"] * sc
+        if o.get("bias"):
+            sh = sh + sd[o["key"] + ".bias"] * sc
+        y = y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        if op.res >= 0:
+            y = y + bufs[op.res].float().cpu().permute(0, 3, 1, 2)
+        if o.get("relu"):
+            y = F.relu(y)
+        ref = y.bfloat16().float().permute(0, 2, 3, 1)
+        assert ref.shape == got.shape, (o["key"], ref.shape, got.shape)
+        diff = (got - ref).abs()
+        # one bf16 ulp (8 significand bits); where the layer's terms cancel to ~0 the two fp32 summation orders differ by
+        # ~2^-24 of the summed magnitudes instead (absolute floor 2e-6)
+        ulp = torch.maximum(ref.abs(), got.abs()) * 2.0 ** -7 + 2e-6
+        if not bool((diff <= ulp).all()):
+            bad = torch.nonzero(diff > ulp)
+            print(o["key"], "bad elements", len(bad), "of", diff.numel(), "first:", [(tuple(int(v) for v in b), float(got[tuple(b)]), float(ref[tuple(b)])) for b in bad[:12]])
+            print("   bad channels", sorted(set(int(b[3]) for b in bad))[:40], "bad rows", sorted(set(int(b[1]) for b in bad))[:20])
+        assert bool((diff <= ulp).all()), (o["key"], float(diff.max()), float((diff / ulp).max()))
+        frac = float((diff > 0).float().mean())
+        worst_frac = max(worst_frac, frac)
+        assert frac < 0.05, (o["key"], frac)
+        assert float(got.abs().max()) > 0
+        checked += 1
+    print(f"backbone single layers: {checked} ops, worst mismatching fraction {worst_frac:.4f} (each within one bf16 ulp)")
+    assert checked == len(want)
+
+
+@pytest.mark.gpu
 def test_zero_batch_through_every_export():
     import edge_cases as E
     E.zero_batch_through_every_export(None, DEV)
