@@ -731,13 +731,56 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   // default: heatmap footprint staged in LDS (fvp_project_lds.h); FVP_TRIPLANE_GATHER=1 selects the first fused
   // kernel (every tap through the texture path) for comparison
   static const bool gather = getenv("FVP_TRIPLANE_GATHER") != nullptr;
+  // FVP_TRIPLANE_QUAD=1: the round-2 form of the LDS-staged kernel (four lanes per voxel) instead of one lane per voxel
+  const bool quad_form = getenv("FVP_TRIPLANE_QUAD") != nullptr;            // read per call: tests switch it
+  // diagnostics (wrong results): 1 no sampling, 2 no tile DMA, 4 no plane maxima, 8 no global-gather fallback
+  static const int tri_ablate_env = getenv("FVP_TRI_ABLATE") ? atoi(getenv("FVP_TRI_ABLATE")) : 0;
+  // bit 16 (NOT a diagnostic: results are identical either way): rectangles that fit the two tiles together are
+  // staged across both when their turn comes instead of being gathered from global memory.  On for the
+  // lane-per-voxel form (its gather reads 64 lines per instruction), off for the quad form (measured 495 -> 515 us:
+  // the quad form's gather runs on the otherwise idle texture path beside the LDS reads of the staged rectangles).
+  // FVP_TRI_TWO_TILE=0/1 overrides.
+  const char* tt_env = getenv("FVP_TRI_TWO_TILE");
+  const bool lane_form = !gather && !quad_form && g->JP <= 20 && g->JP != 16;
+  const int tri_ablate = (tri_ablate_env & ~16) | ((tt_env ? atoi(tt_env) != 0 : lane_form) ? 16 : 0);
+  // tests: FVP_TRI_CAP_PX lowers the rectangle size the kernel treats as fitting a tile (the allocation is unchanged),
+  // so that one-tile, two-tile and global-gather rectangles all occur on small fixtures; read per call
+  auto cap_lim = [](int cap) { const char* e = getenv("FVP_TRI_CAP_PX"); const int v = e ? atoi(e) : cap; return v > 0 && v < cap ? v : cap; };
+  const int F0 = fine_grid ? fine[0] : 0, F1 = fine_grid ? fine[1] : 0, F2 = fine_grid ? fine[2] : 0;
+  const int nbx = ceil_div(C, kBX), nby = ceil_div(C, kBY);
+  // two tiles per workgroup, two workgroups (512 threads, <= 128 VGPRs) per CU: 4 x 36 KB + state
+  const int cap_px = int((36 * 1024) / (size_t(g->JP) * 4));
+  const size_t lds = 2 * size_t(cap_px) * g->JP * 4 + 64;
+  // lane-per-voxel form for JP = 4 .. 12 and 20 (J = 17: Shelf / Campus, where the quad form needs two channel quads per
+  // lane and 16-deep blocks): Campus 222 -> 160 us, Shelf 756 -> 714 us for 80 / 40 people.  JP = 16 (Panoptic) stays
+  // on the quad form (490 vs 616 us: more than half of its rectangles exceed a tile and are gathered, which the quad
+  // form does with 4x fewer cache lines per instruction); JP 24 .. 32 would spill.  FVP_TRIPLANE_LANE=1 forces it.
+  static const bool force_lane = getenv("FVP_TRIPLANE_LANE") != nullptr;
+  if (lane_form || (force_lane && !gather && g->JP <= 20)) {
+    const int lq = (g->JP / 4) | 1;                                           // tile pixel pitch in quads (odd)
+    const int cap_px = int((36 * 1024) / (size_t(lq) * 16));
+    const size_t lds = 2 * size_t(cap_px) * lq * 16 + 64;
+    FVP_LIMIT(size_t(cap_px) * lq * 4 >= size_t(kBX * kBY + (kBX + kBY) * 32) * g->JP);   // the block's plane cells alias tile 0
+#define CALL2(NQ_, CACHED_)                                                                                       \
+  {                                                                                                                \
+    static LdsOptIn optin;                                                                                         \
+    auto k = &k_project_triplane_lds2<NQ_, CACHED_>;                                                              \
+    if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds)) return e;                                \
+    hipLaunchKernelGGL(k, dim3(nbx * nby * nP), dim3(kTriThreads), lds, as_stream(s), heat_cl,                     \
+                       reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, \
+                       nP, nbx, nby, ppf, cap_px, *g, fine_grid, F0, F1, F2, planes, tri_ablate, cap_lim(cap_px));                  \
+  }
+#define CASE2(NQ_) case NQ_: if (fine_grid) CALL2(NQ_, true) else CALL2(NQ_, false) break;
+    switch (g->JP / 4) {
+      CASE2(1) CASE2(2) CASE2(3) CASE2(4) CASE2(5)
+      default: return FVP_ELIMIT;
+    }
+#undef CASE2
+#undef CALL2
+    return launch_status();
+  }
   if (!gather && nvl <= 2) {
-    const int nbx = ceil_div(C, kBX), nby = ceil_div(C, kBY);
-    // two tiles per workgroup, two workgroups (512 threads, <= 128 VGPRs) per CU: 4 x 36 KB + state
-    const int cap_px = int((36 * 1024) / (size_t(g->JP) * 4));
     FVP_LIMIT(cap_px >= kBX * kBY + (kBX + kBY) * (nvl == 1 ? 32 : 16));      // the block's plane cells alias tile 0
-    const size_t lds = 2 * size_t(cap_px) * g->JP * 4 + 64;
-    const int F0 = fine_grid ? fine[0] : 0, F1 = fine_grid ? fine[1] : 0, F2 = fine_grid ? fine[2] : 0;
 #define CALL(NVL_, CACHED_)                                                                                        \
   {                                                                                                                \
     static LdsOptIn optin;                                                                                         \
@@ -745,7 +788,7 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
     if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds)) return e;                                \
     hipLaunchKernelGGL(k, dim3(nbx * nby * nP), dim3(kTriThreads), lds, as_stream(s), heat_cl,                     \
                        reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, \
-                       nP, nbx, nby, ppf, cap_px, *g, fine_grid, F0, F1, F2, planes);                              \
+                       nP, nbx, nby, ppf, cap_px, *g, fine_grid, F0, F1, F2, planes, tri_ablate, cap_lim(cap_px));                  \
   }
     if (nvl == 1) {
       if (fine_grid) CALL(1, true) else CALL(1, false)

@@ -25,6 +25,11 @@
 
 namespace fvp {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef FVP_TRI_PACKED
+#define FVP_TRI_PACKED 1
+#endif
+
 struct TapL {      // tap descriptor of one (voxel, view), relative to the staged rectangle
   int base;        // float offset of the nw tap's pixel (clamped into the rectangle), channel 0, in the LDS tile
   int dx, dy;      // float offsets nw -> ne and nw -> sw (0 where the neighbour is clamped onto the same pixel)
@@ -72,6 +77,10 @@ __device__ __forceinline__ int row_max(int v) {
   return v;
 }
 
+// Plane cell update: integer atomicMax on the non-negative float (fire and forget).  Reading the cell first and issuing
+// the atomic only when it would win was measured slower (490 -> 533 us): the phase is latency-bound, not atomic-bound.
+__device__ __forceinline__ void plane_max(float* cell, int vv) { atomicMax(reinterpret_cast<int*>(cell), vv); }
+
 constexpr int kBX = 8, kBY = 4;                 // voxel block of a workgroup in x, y; in z: 32 (one channel quad per
                                                // lane) or 16 (two: J = 17), so that both forms stay within 128 VGPRs
 constexpr int kTriThreads = kBX * kBY * 4 * 4; // (x, y, zs) slots x 4 channel-quad lanes = 512
@@ -85,7 +94,7 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
                        const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
                        const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
                        const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, int cap_px, FvpGeom g,
-                       const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes) {
+                       const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes, int ablate, int cap_lim) {
   constexpr int BZ = NVL == 1 ? 32 : 16;            // z extent of the voxel block
   constexpr int VPT = BZ / 4;                        // voxels per thread: z = zs + 4 i
   constexpr int OWN = VPT / 4;                       // voxels a lane projects per view (i = q + 4 k)
@@ -186,7 +195,9 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
       atomicMax(&rc[0], mnx); atomicMax(&rc[1], mxx); atomicMax(&rc[2], mny); atomicMax(&rc[3], mxy);
     }
   };
-  struct Rect { int x0, y0, w, h, pitch; bool any, staged; };
+  // staged: fits one tile (DMA issued one view ahead); big: fits the two tiles together (staged when its turn comes,
+  // nothing overlapped); neither: sampled from global memory
+  struct Rect { int x0, y0, w, h, pitch; bool any, staged, big, lds; };
   auto read_rect = [&](int v) {
     const int* rc = rect + 4 * (v % 3);
     // workgroup-uniform values: keep them in scalar registers
@@ -199,14 +210,16 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
     r.w = r.any ? c1 - r.x0 + 1 : 0;
     r.h = r.any ? c3 - r.y0 + 1 : 0;
     r.pitch = r.w | 1;                                                   // odd pixel pitch: rows start in different bank quarters
-    r.staged = r.any && r.h * r.pitch <= cap_px;
+    r.staged = r.any && r.h * r.pitch <= cap_lim;                        // cap_lim = cap_px (tests may lower it)
+    r.big = r.any && !r.staged && r.h * r.pitch <= 2 * cap_lim && (ablate & 16);
+    r.lds = r.staged || r.big;
     return r;
   };
   // rectangle -> LDS tile, rows of pitch * JP floats.  A wave copies rows wave, wave + NW, ...: one LDS-DMA
   // instruction per 64 quads of a row (lane = quad, so no index division; the pad column re-reads the last pixel)
   auto issue_dma = [&](int v, const Rect& r) {
-    if (!r.staged) return;
-    float* tile = smem + (v & 1) * tile_sz;
+    if (!r.lds || (ablate & 2)) return;
+    float* tile = r.big ? smem : smem + (v & 1) * tile_sz;
     const float* plane = frame + size_t(v) * view_stride + (size_t(r.y0) * W + r.x0) * JP;
     const int pq = r.pitch * qn;                                         // quads per tile row
     for (int c0 = 0; c0 < pq; c0 += 64) {
@@ -226,9 +239,9 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
   auto finish = [&](const Own& o, int k, const Rect& r) {
     TapL d;
     const int x0 = (o.xy[k] << 16) >> 16, y0 = o.xy[k] >> 16;
-    const int rx0 = r.staged ? r.x0 : 0, ry0 = r.staged ? r.y0 : 0;
-    const int rx1 = r.staged ? r.x0 + r.w - 1 : W - 1, ry1 = r.staged ? r.y0 + r.h - 1 : H - 1;
-    const int pitch = r.staged ? r.pitch : W;
+    const int rx0 = r.lds ? r.x0 : 0, ry0 = r.lds ? r.y0 : 0;
+    const int rx1 = r.lds ? r.x0 + r.w - 1 : W - 1, ry1 = r.lds ? r.y0 + r.h - 1 : H - 1;
+    const int pitch = r.lds ? r.pitch : W;
     const int cx0 = imin(imax(x0, rx0), rx1), cx1 = imin(imax(x0 + 1, rx0), rx1);
     const int cy0 = imin(imax(y0, ry0), ry1), cy1 = imin(imax(y0 + 1, ry0), ry1);
     d.base = ((cy0 - ry0) * pitch + (cx0 - rx0)) * JP;
@@ -255,7 +268,7 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
     project(0, gz0, cur);
     __syncthreads();
     Rect rcur = read_rect(0);
-    issue_dma(0, rcur);
+    if (rcur.staged) issue_dma(0, rcur);                                 // (a two-tile rectangle is staged inside the loop)
     if (CACHED && V > 1) load_coords(1, gz0);
     for (int v = 0; v < V; ++v) {
       if (v + 1 < V) project(v + 1, gz0, nxt);                           // overlaps view v's DMA
@@ -263,15 +276,21 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
       __syncthreads();                                                   // view v staged for everybody; rectangle v+1 complete;
                                                                          // tile (v+1)&1 is free (view v-1 has been sampled)
       Rect rnxt = rcur;
-      if (v + 1 < V) {
-        rnxt = read_rect(v + 1);
-        issue_dma(v + 1, rnxt);
+      if (v + 1 < V) rnxt = read_rect(v + 1);
+      if (rcur.big) {
+        // view v's rectangle needs both tiles: they are free now (view v-1 has been sampled, view v+1 is not issued)
+        issue_dma(v, rcur);
+        if (CACHED && v + 2 < V) load_coords(v + 2, gz0);
+        wait_vmcnt(0);
+        __syncthreads();
+      } else if (v + 1 < V) {
+        if (rnxt.staged) issue_dma(v + 1, rnxt);                         // overlaps the sampling of view v
         if (CACHED && v + 2 < V) load_coords(v + 2, gz0);                // consumed by the next iteration's project()
       }
       if (t < 4) rect[4 * (v % 3) + t] = INT_MIN;                        // slot of view v (= view v+3): all its readers passed the barrier
       // ---- sample the thread's 8 voxels of view v (owner lane i & 3 holds the descriptor of voxel i)
-      if (rcur.any) {
-        const float* src = rcur.staged ? smem + (v & 1) * tile_sz : frame + size_t(v) * view_stride;
+      if (rcur.any && !(ablate & 1) && (rcur.lds || !(ablate & 8))) {   // (8: skip the global-gather fallback)
+        const float* src = rcur.big ? smem : (rcur.staged ? smem + (v & 1) * tile_sz : frame + size_t(v) * view_stride);
         auto sample = [&](const TapL& tv, float (&a)[NVL][4]) {
 #pragma unroll
           for (int n = 0; n < NVL; ++n) {
@@ -282,6 +301,20 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
               const float4 v1 = *reinterpret_cast<const float4*>(p0 + tv.dx);
               const float4 v2 = *reinterpret_cast<const float4*>(p0 + tv.dy);
               const float4 v3 = *reinterpret_cast<const float4*>(p0 + tv.dy + tv.dx);
+#if FVP_TRI_PACKED
+              // packed fp32 on register pairs: IEEE per element, the same operation order per channel (same bits)
+              const f32x2 w0 = f32x2{tv.w[0], tv.w[0]}, w1 = f32x2{tv.w[1], tv.w[1]}, w2 = f32x2{tv.w[2], tv.w[2]},
+                          w3 = f32x2{tv.w[3], tv.w[3]};
+              f32x2 lo = f32x2{v0.x, v0.y} * w0, hi = f32x2{v0.z, v0.w} * w0;
+              lo = __builtin_elementwise_fma(f32x2{v1.x, v1.y}, w1, lo);
+              hi = __builtin_elementwise_fma(f32x2{v1.z, v1.w}, w1, hi);
+              lo = __builtin_elementwise_fma(f32x2{v2.x, v2.y}, w2, lo);
+              hi = __builtin_elementwise_fma(f32x2{v2.z, v2.w}, w2, hi);
+              lo = __builtin_elementwise_fma(f32x2{v3.x, v3.y}, w3, lo);
+              hi = __builtin_elementwise_fma(f32x2{v3.z, v3.w}, w3, hi);
+              const f32x2 alo = f32x2{a[n][0], a[n][1]} + lo, ahi = f32x2{a[n][2], a[n][3]} + hi;
+              a[n][0] = alo.x; a[n][1] = alo.y; a[n][2] = ahi.x; a[n][3] = ahi.y;
+#else
               float s0_ = __fmul_rn(v0.x, tv.w[0]), s1_ = __fmul_rn(v0.y, tv.w[0]);
               float s2_ = __fmul_rn(v0.z, tv.w[0]), s3_ = __fmul_rn(v0.w, tv.w[0]);
               s0_ = __fmaf_rn(v1.x, tv.w[1], s0_); s1_ = __fmaf_rn(v1.y, tv.w[1], s1_);
@@ -292,6 +325,7 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
               s2_ = __fmaf_rn(v3.z, tv.w[3], s2_); s3_ = __fmaf_rn(v3.w, tv.w[3], s3_);
               a[n][0] = __fadd_rn(a[n][0], s0_); a[n][1] = __fadd_rn(a[n][1], s1_);
               a[n][2] = __fadd_rn(a[n][2], s2_); a[n][3] = __fadd_rn(a[n][3], s3_);
+#endif
             }
           }
         };
@@ -304,18 +338,26 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
           { const TapL tv = quad_bcast_l<3>(mine); sample(tv, acc[4 * k + 3]); }
         }
       }
+      if (rcur.big) {
+        __syncthreads();                                                 // everybody is done with the two-tile rectangle
+        if (v + 1 < V && rnxt.staged) issue_dma(v + 1, rnxt);            // (not overlapped: the rare path)
+      }
       cur = nxt;
       rcur = rnxt;
     }
     // ---- mean over views, clamp, block maxima through LDS (tile 0 is free: every sampler passes the barrier
     //      below), then into the global planes
     __syncthreads();
+    if (ablate & 4) continue;                                            // diagnostics (FVP_TRI_ABLATE): uniform
     int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JP]
     int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][BZ][JP]
     int* cyz = cxz + kBX * BZ * JP;                                     // [kBY][BZ][JP]
     const int ncell = (kBX * kBY + (kBX + kBY) * BZ) * JP;              // <= cap_px * JP (checked by the host)
     for (int i = t; i < ncell; i += NT) cxy[i] = 0;
     __syncthreads();
+    // The block's maxima are taken over the RAW view sums (clamped at 0 so that they order like ints); mean and clamp
+    // are applied once per plane cell below: v -> clamp(v / V, 0, 1) is monotone, so max commutes with it and the planes
+    // are bit-equal to dividing every voxel first (16 384 IEEE divisions per block pass became 6 240).
 #pragma unroll
     for (int n = 0; n < NVL; ++n)
 #pragma unroll
@@ -324,7 +366,7 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
         float mz = 0.0f;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-          const float val = clampf(__fdiv_rn(acc[i][n][c], nv), 0.0f, 1.0f);
+          const float val = fmaxf(acc[i][n][c], 0.0f);
           mz = fmaxf(mz, val);
           if (val > 0.0f && ch < JP) {
             const int z = zs + 4 * i;
@@ -342,24 +384,317 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
     const int lz0 = gz0 - tl2;
     for (int i = t; i < kBX * kBY * J; i += NT) {                        // xy: cell (x, y) of channel ch
       const int ch = i / (kBX * kBY), col = i - ch * (kBX * kBY), cx = col / kBY, cy = col - cx * kBY;
-      const int vv = cxy[col * JP + ch];
-      if (vv > 0 && gx0 + cx < e0 && gy0 + cy < e1)
-        atomicMax(reinterpret_cast<int*>(&pxy[size_t(ch) * CC + (gx0 + cx - tl0) * C + (gy0 + cy - tl1)]), vv);
+      const int raw = cxy[col * JP + ch];
+      if (raw > 0 && gx0 + cx < e0 && gy0 + cy < e1) {
+        const int vv = __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f));
+        if (vv > 0) plane_max(&pxy[size_t(ch) * CC + (gx0 + cx - tl0) * C + (gy0 + cy - tl1)], vv);
+      }
     }
     for (int i = t; i < (kBX + kBY) * BZ * J; i += NT) {                // xz then yz rows: z fastest
       const int ch = i / ((kBX + kBY) * BZ), r = i - ch * ((kBX + kBY) * BZ), a = r / BZ, z = r - a * BZ;
       if (gz0 + z < e2) {
-        const int vv = cxz[r * JP + ch];                                 // rows kBX.. continue into cyz
+        const int raw = cxz[r * JP + ch];                                // rows kBX.. continue into cyz
+        const int vv = raw > 0 ? __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f)) : 0;
         if (vv > 0) {
           if (a < kBX) {
-            if (gx0 + a < e0) atomicMax(reinterpret_cast<int*>(&pxz[size_t(ch) * CC + (gx0 + a - tl0) * C + lz0 + z]), vv);
+            if (gx0 + a < e0) plane_max(&pxz[size_t(ch) * CC + (gx0 + a - tl0) * C + lz0 + z], vv);
           } else if (gy0 + a - kBX < e1) {
-            atomicMax(reinterpret_cast<int*>(&pyz[size_t(ch) * CC + (gy0 + a - kBX - tl1) * C + lz0 + z]), vv);
+            plane_max(&pyz[size_t(ch) * CC + (gy0 + a - kBX - tl1) * C + lz0 + z], vv);
           }
         }
       }
     }
     __syncthreads();                                                     // the tiles are reused by the next z block
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same kernel with ONE LANE PER VOXEL (all JP channels) instead of four lanes per voxel (a channel quad
+// each).  Ablations of the quad form (80 people, FVP_TRI_ABLATE): 494 us complete = 225 us sampling + 104 us
+// plane maxima + ~175 us skeleton (projection, rectangles, barriers); the tile DMA is hidden (15 us).  The sampling is
+// issue-bound, and most of what it issues is not arithmetic: a (voxel, view) costs 4 lanes x (4 ds_read_b128 + 20 VALU +
+// 7 DPP broadcasts of the tap descriptor + address adds) = ~150 lane-instructions.  The quad form was right for the
+// round-1 kernel that gathered through the texture path (a quad reads 64 contiguous bytes: 4x fewer cache lines per
+// instruction); from LDS a ds_read_b128 costs the same whichever lanes issue it.  With a lane per voxel the descriptor
+// stays in the lane that computed it (no broadcasts), the four taps of a channel quad are packed-fp32 operations on
+// register pairs (v_pk_mul / v_pk_fma / v_pk_add: IEEE per element, same operation order per channel, so the same
+// bits), and a (voxel, view) is NQ x (4 ds_read_b128 + 10 packed VALU) + a few address adds = ~60 lane-instructions.
+// Thread t: z16 = t & 15, y = (t >> 4) & 3, x = t >> 6 (= wave), voxels z16 and z16 + 16 of the 8 x 4 x 32 block.
+template <int NQ, bool CACHED>   // NQ = JP / 4 channel quads per pixel
+__global__ void __launch_bounds__(kTriThreads, 4)
+k_project_triplane_lds2(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
+                        const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
+                        const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
+                        const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, int cap_px, FvpGeom g,
+                        const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes, int ablate, int cap_lim) {
+  constexpr int BZ = 32, VPT = 2, JP = 4 * NQ;
+  // pixel pitch in the LDS tile: an ODD number of 16-byte quads (JP = 16: 80 bytes, the fifth quad is padding), so that
+  // the 64 lanes of a ds_read_b128 - each at its own pixel - spread over all bank groups (with the 64-byte pitch of
+  // the global layout they hit 4 of the 16: measured 668 us against 490 for the quad form)
+  constexpr int LQ = NQ | 1, LP = 4 * LQ;
+  HIP_DYNAMIC_SHARED(float, smem)
+  constexpr int NT = kTriThreads;
+  const int J = g.J, CC = C * C, V = g.V, W = g.W, H = g.H;
+  const int tile_sz = cap_px * LP;
+  int* rect = reinterpret_cast<int*>(smem + 2 * size_t(tile_sz));        // [3][4]: -minx, maxx, -miny, maxy
+  int p, blk;
+  {
+    const int id = blockIdx.x;
+    const int bpp = nbx * nby, bpf = ppf * bpp;
+    const int nframes = nP / ppf;
+    if (nframes % 8 == 0) {
+      const int xcd = id & 7, j = id >> 3;
+      const int frame = xcd + 8 * (j / bpf), r = j % bpf;
+      p = frame * ppf + r / bpp;
+      blk = r % bpp;
+    } else {
+      p = id / bpp;
+      blk = id % bpp;
+    }
+  }
+  if (person_valid && !person_valid[p]) return;
+  const int* bx = boxes + p * 9;
+  const int tl0 = bx[0], tl1 = bx[1], tl2 = bx[2];
+  const int s0 = bx[3], s1 = bx[4], s2 = bx[5], e0 = bx[6], e1 = bx[7], e2 = bx[8];
+  if (s0 >= e0 || s1 >= e1 || s2 >= e2) return;
+  const int xb = blk / nby, yb = blk - xb * nby;
+  const int gx0 = s0 + xb * kBX, gy0 = s1 + yb * kBY;
+  if (gx0 >= e0 || gy0 >= e1) return;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int z16 = t & 15, yy = (t >> 4) & (kBY - 1), xx = t >> 6;
+  const int gxi = gx0 + xx, gyi = gy0 + yy;
+  const bool col_in = gxi < e0 && gyi < e1;
+  const int b = person_frame[p];
+  const size_t view_stride = size_t(H) * W * JP;
+  const float* frame = heat_cl + size_t(b) * V * view_stride;
+  const Cam* cm = cams + size_t(frame_set[b]) * V;
+  const float wx = col_in ? fx[gxi] : 0.0f, wy = col_in ? fy[gyi] : 0.0f;
+  const size_t nfine = size_t(F0) * F1 * F2;
+  const float2* gcol = CACHED ? reinterpret_cast<const float2*>(fgrid) + size_t(frame_set[b]) * V * nfine +
+                                    (size_t(col_in ? gxi : 0) * F1 + (col_in ? gyi : 0)) * F2
+                              : nullptr;
+  float* pxy = planes + (size_t(p) * 3 + 0) * J * CC;
+  float* pxz = planes + (size_t(p) * 3 + 1) * J * CC;
+  float* pyz = planes + (size_t(p) * 3 + 2) * J * CC;
+  const float nv = float(V);
+
+  struct Own { int xy[VPT]; int inside[VPT]; float w[VPT][4]; };
+  float2 crd[VPT];
+  auto load_coords = [&](int v, int gz0) {
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int gzi = gz0 + z16 + 16 * k;
+      crd[k] = gcol[size_t(v) * nfine + (gzi < F2 ? gzi : F2 - 1)];
+    }
+  };
+  auto project = [&](int v, int gz0, Own& o) {
+    int mnx = INT_MIN, mxx = INT_MIN, mny = INT_MIN, mxy = INT_MIN;     // (-min, max) pairs
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int gzi = gz0 + z16 + 16 * k;
+      const bool vin = col_in && gzi < e2;
+      o.inside[k] = 0;
+      o.xy[k] = 0;
+      o.w[k][0] = o.w[k][1] = o.w[k][2] = o.w[k][3] = 0.0f;
+      if (vin) {
+        float sx, sy;
+        if (CACHED) {
+          sx = crd[k].x;
+          sy = crd[k].y;
+        } else {
+          project_norm(cm[v], g, wx, wy, fz[gzi], sx, sy);
+        }
+        int x0, y0;
+        tap_origin(sx, sy, W, H, x0, y0, o.w[k], o.inside[k]);
+        o.xy[k] = int((unsigned(y0) << 16) | (unsigned(x0) & 0xffffu));
+        if (o.inside[k]) {
+          mnx = imax(mnx, -imax(x0, 0)); mxx = imax(mxx, imin(x0 + 1, W - 1));
+          mny = imax(mny, -imax(y0, 0)); mxy = imax(mxy, imin(y0 + 1, H - 1));
+        }
+      }
+    }
+    mnx = row_max(mnx); mxx = row_max(mxx); mny = row_max(mny); mxy = row_max(mxy);
+    if ((lane & 15) == 0 && mxx != INT_MIN) {
+      int* rc = rect + 4 * (v % 3);
+      atomicMax(&rc[0], mnx); atomicMax(&rc[1], mxx); atomicMax(&rc[2], mny); atomicMax(&rc[3], mxy);
+    }
+  };
+  // staged: fits one tile (DMA issued one view ahead); big: fits the two tiles together (staged when its turn comes,
+  // nothing overlapped); neither: sampled from global memory
+  struct Rect { int x0, y0, w, h, pitch; bool any, staged, big, lds; };
+  auto read_rect = [&](int v) {
+    const int* rc = rect + 4 * (v % 3);
+    const int c0 = __builtin_amdgcn_readfirstlane(rc[0]), c1 = __builtin_amdgcn_readfirstlane(rc[1]);
+    const int c2 = __builtin_amdgcn_readfirstlane(rc[2]), c3 = __builtin_amdgcn_readfirstlane(rc[3]);
+    Rect r;
+    r.any = c1 != INT_MIN;
+    r.x0 = r.any ? -c0 : 0;
+    r.y0 = r.any ? -c2 : 0;
+    r.w = r.any ? c1 - r.x0 + 1 : 0;
+    r.h = r.any ? c3 - r.y0 + 1 : 0;
+    r.pitch = r.w | 1;
+    r.staged = r.any && r.h * r.pitch <= cap_lim;                        // cap_lim = cap_px (tests may lower it)
+    r.big = r.any && !r.staged && r.h * r.pitch <= 2 * cap_lim && (ablate & 16);
+    r.lds = r.staged || r.big;
+    return r;
+  };
+  auto issue_dma = [&](int v, const Rect& r) {
+    if (!r.lds || (ablate & 2)) return;
+    float* tile = r.big ? smem : smem + (v & 1) * tile_sz;
+    const float* plane = frame + size_t(v) * view_stride + (size_t(r.y0) * W + r.x0) * JP;
+    const int pq = r.pitch * LQ;                                         // quads per tile row (incl. the padding quads)
+    for (int c0 = 0; c0 < pq; c0 += 64) {
+      const int col = c0 + lane;
+      int px = col / LQ;                                                 // LQ is a compile-time constant
+      int cq = col - px * LQ;
+      cq = cq < NQ ? cq : NQ - 1;                                        // padding quad: re-read the last one
+      px = px < r.w ? px : r.w - 1;
+      const float* src0 = plane + size_t(px) * JP + 4 * cq;
+      for (int row = wave; row < r.h; row += NT / 64) {
+        if (col < pq)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + size_t(row) * W * JP),
+                                           (__attribute__((address_space(3))) void*)(tile + size_t(row * pq + c0) * 4), 16, 0, 0);
+      }
+    }
+  };
+  auto finish = [&](const Own& o, int k, const Rect& r) {
+    TapL d;
+    const int x0 = (o.xy[k] << 16) >> 16, y0 = o.xy[k] >> 16;
+    const int rx0 = r.lds ? r.x0 : 0, ry0 = r.lds ? r.y0 : 0;
+    const int rx1 = r.lds ? r.x0 + r.w - 1 : W - 1, ry1 = r.lds ? r.y0 + r.h - 1 : H - 1;
+    const int pitch = r.lds ? r.pitch : W;
+    const int ps = r.lds ? LP : JP;                                   // floats per pixel: LDS tile / global plane
+    const int cx0 = imin(imax(x0, rx0), rx1), cx1 = imin(imax(x0 + 1, rx0), rx1);
+    const int cy0 = imin(imax(y0, ry0), ry1), cy1 = imin(imax(y0 + 1, ry0), ry1);
+    d.base = ((cy0 - ry0) * pitch + (cx0 - rx0)) * ps;
+    d.dx = (cx1 - cx0) * ps;
+    d.dy = (cy1 - cy0) * pitch * ps;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d.w[c] = ((o.inside[k] >> c) & 1) ? o.w[k][c] : 0.0f;
+    return d;
+  };
+
+  for (int gz0 = s2; gz0 < e2; gz0 += BZ) {
+    if (t < 12) rect[t] = INT_MIN;
+    __syncthreads();
+    f32x2 acc[VPT][2 * NQ];                                              // channel pairs
+#pragma unroll
+    for (int k = 0; k < VPT; ++k)
+#pragma unroll
+      for (int c = 0; c < 2 * NQ; ++c) acc[k][c] = f32x2{0.0f, 0.0f};
+
+    Own cur, nxt;
+    if (CACHED) load_coords(0, gz0);
+    project(0, gz0, cur);
+    __syncthreads();
+    Rect rcur = read_rect(0);
+    if (rcur.staged) issue_dma(0, rcur);                                 // (a two-tile rectangle is staged inside the loop)
+    if (CACHED && V > 1) load_coords(1, gz0);
+    for (int v = 0; v < V; ++v) {
+      if (v + 1 < V) project(v + 1, gz0, nxt);
+      wait_vmcnt(0);
+      __syncthreads();
+      Rect rnxt = rcur;
+      if (v + 1 < V) rnxt = read_rect(v + 1);
+      if (rcur.big) {
+        // view v's rectangle needs both tiles: they are free now (view v-1 has been sampled, view v+1 is not issued)
+        issue_dma(v, rcur);
+        if (CACHED && v + 2 < V) load_coords(v + 2, gz0);
+        wait_vmcnt(0);
+        __syncthreads();
+      } else if (v + 1 < V) {
+        if (rnxt.staged) issue_dma(v + 1, rnxt);                         // overlaps the sampling of view v
+        if (CACHED && v + 2 < V) load_coords(v + 2, gz0);                // consumed by the next iteration's project()
+      }
+      if (t < 4) rect[4 * (v % 3) + t] = INT_MIN;                        // slot of view v (= view v+3): all its readers passed the barrier
+      if (rcur.any && !(ablate & 1) && (rcur.lds || !(ablate & 8))) {   // (8: skip the global-gather fallback)
+        const float* src = rcur.big ? smem : (rcur.staged ? smem + (v & 1) * tile_sz : frame + size_t(v) * view_stride);
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+          const TapL d = finish(cur, k, rcur);
+          const float* p0 = src + d.base;
+          const f32x2 w0 = f32x2{d.w[0], d.w[0]}, w1 = f32x2{d.w[1], d.w[1]}, w2 = f32x2{d.w[2], d.w[2]},
+                      w3 = f32x2{d.w[3], d.w[3]};
+#pragma unroll
+          for (int n = 0; n < NQ; ++n) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p0 + 4 * n);
+            const float4 v1 = *reinterpret_cast<const float4*>(p0 + d.dx + 4 * n);
+            const float4 v2 = *reinterpret_cast<const float4*>(p0 + d.dy + 4 * n);
+            const float4 v3 = *reinterpret_cast<const float4*>(p0 + d.dy + d.dx + 4 * n);
+            // per channel: nw * w0, then fma(ne), fma(sw), fma(se), then the view-ordered add (the reference's order)
+            f32x2 lo = f32x2{v0.x, v0.y} * w0, hi = f32x2{v0.z, v0.w} * w0;
+            lo = __builtin_elementwise_fma(f32x2{v1.x, v1.y}, w1, lo);
+            hi = __builtin_elementwise_fma(f32x2{v1.z, v1.w}, w1, hi);
+            lo = __builtin_elementwise_fma(f32x2{v2.x, v2.y}, w2, lo);
+            hi = __builtin_elementwise_fma(f32x2{v2.z, v2.w}, w2, hi);
+            lo = __builtin_elementwise_fma(f32x2{v3.x, v3.y}, w3, lo);
+            hi = __builtin_elementwise_fma(f32x2{v3.z, v3.w}, w3, hi);
+            acc[k][2 * n] = acc[k][2 * n] + lo;
+            acc[k][2 * n + 1] = acc[k][2 * n + 1] + hi;
+          }
+        }
+      }
+      if (rcur.big) {
+        __syncthreads();                                                 // everybody is done with the two-tile rectangle
+        if (v + 1 < V && rnxt.staged) issue_dma(v + 1, rnxt);            // (not overlapped: the rare path)
+      }
+      cur = nxt;
+      rcur = rnxt;
+    }
+    __syncthreads();
+    if (ablate & 4) continue;
+    int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JP]
+    int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][BZ][JP]
+    int* cyz = cxz + kBX * BZ * JP;                                      // [kBY][BZ][JP]
+    constexpr int ncell = (kBX * kBY + (kBX + kBY) * BZ) * JP;           // <= cap_px * JP (checked by the host)
+    for (int i = t; i < ncell; i += NT) cxy[i] = 0;
+    __syncthreads();
+    // maxima over the raw view sums (clamped at 0); mean + clamp once per plane cell below (monotone: same bits)
+#pragma unroll
+    for (int c2 = 0; c2 < 2 * NQ; ++c2)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ch = 2 * c2 + e;
+        float mz = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+          const float val = fmaxf(e ? acc[k][c2].y : acc[k][c2].x, 0.0f);
+          mz = fmaxf(mz, val);
+          if (val > 0.0f) {
+            const int z = z16 + 16 * k;
+            atomicMax(&cxz[(xx * BZ + z) * JP + ch], __float_as_int(val));
+            atomicMax(&cyz[(yy * BZ + z) * JP + ch], __float_as_int(val));
+          }
+        }
+        const int mi = row_max(__float_as_int(mz));                      // the 16 z-lanes of a column are one DPP row
+        if (z16 == 0 && mi > 0) cxy[(xx * kBY + yy) * JP + ch] = mi;
+      }
+    __syncthreads();
+    const int lz0 = gz0 - tl2;
+    for (int i = t; i < kBX * kBY * J; i += NT) {
+      const int ch = i / (kBX * kBY), col = i - ch * (kBX * kBY), cx = col / kBY, cy = col - cx * kBY;
+      const int raw = cxy[col * JP + ch];
+      if (raw > 0 && gx0 + cx < e0 && gy0 + cy < e1) {
+        const int vv = __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f));
+        if (vv > 0) plane_max(&pxy[size_t(ch) * CC + (gx0 + cx - tl0) * C + (gy0 + cy - tl1)], vv);
+      }
+    }
+    for (int i = t; i < (kBX + kBY) * BZ * J; i += NT) {
+      const int ch = i / ((kBX + kBY) * BZ), r = i - ch * ((kBX + kBY) * BZ), a = r / BZ, z = r - a * BZ;
+      if (gz0 + z < e2) {
+        const int raw = cxz[r * JP + ch];
+        const int vv = raw > 0 ? __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f)) : 0;
+        if (vv > 0) {
+          if (a < kBX) {
+            if (gx0 + a < e0) plane_max(&pxz[size_t(ch) * CC + (gx0 + a - tl0) * C + lz0 + z], vv);
+          } else if (gy0 + a - kBX < e1) {
+            plane_max(&pyz[size_t(ch) * CC + (gy0 + a - kBX - tl1) * C + lz0 + z], vv);
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -247,3 +247,27 @@ def test_split_k_direct_conv_on_small_maps(emu_lib, cin, cmid, hw, planes):
     got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)[o]
     want = ref(x)
     np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("quad", [False, True])
+@pytest.mark.parametrize("cap", [12, 40, 100])
+def test_fused_projection_one_tile_two_tile_and_gather_rectangles(emu_lib, monkeypatch, cap, quad):
+    """The LDS-staged fused projection treats a (block, view) rectangle in one of three ways: it fits one tile (DMA one
+    view ahead), it fits the two tiles together (staged when its turn comes, round 3), or it is gathered from global
+    memory.  FVP_TRI_CAP_PX shrinks the size the kernel regards as fitting so that all three occur on the miniature
+    fixture; the planes must stay bit-equal to the materialised path whatever the mix - for the lane-per-voxel form
+    and for the four-lanes-per-voxel form (FVP_TRIPLANE_QUAD)."""
+    case = "tiny_g_b2_all"
+    model, cfg, cams, seq, rt, heat, meta = build_model(case, emu_lib)
+    with torch.no_grad():
+        model.joint_net.fused_projection = False
+        model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        want = model.engine.last_jln["planes"].clone()
+        model.joint_net.fused_projection = True
+        monkeypatch.setenv("FVP_TRI_CAP_PX", str(cap))
+        monkeypatch.setenv("FVP_TRI_TWO_TILE", "1")
+        if quad:
+            monkeypatch.setenv("FVP_TRIPLANE_QUAD", "1")
+        model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+        got = model.engine.last_jln["planes"].clone()
+    assert want.abs().sum() > 0 and torch.equal(got, want)
