@@ -218,3 +218,62 @@ def test_bench_launcher_without_enough_gpus_exits_cleanly():
                        text=True, timeout=300)
     assert r.returncode == 3 and "needs 2 visible GPUs" in r.stderr and "Traceback" not in r.stderr
     assert r.stdout.strip() == ""
+
+
+def _worker_real_path(rank, world, port, q):
+    """One rank of the frame-sharded job with the REAL hot path (the unmodified kernels on the CPU emulator)."""
+    import ctypes
+    import subprocess
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("FVP_WINO_GENERIC", "1")
+    for p_ in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cases import make_inputs, make_weights
+    from faster_voxelpose_amd import _capi as capi
+    from faster_voxelpose_amd.core import distributed as D
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    here = os.path.join(ROOT, "tests", "hipemu")
+    if rank == 0:
+        subprocess.run([os.path.join(here, "build_emu.sh")], check=True, capture_output=True)
+    dist.barrier()
+    lib = capi.bind(ctypes.CDLL(os.path.join(here, "libfvp_emu.so")))
+    case = "tiny_u_b3_thr"                                   # 3 frames in the fixture: use frames 0..1 per rank below
+    cfg, cams, seq, rt, heat, meta, _ = make_inputs(case)
+    model = FV.FasterVoxelPoseNet(cfg, _lib=lib)
+    model.load_state_dict(make_weights(case, model.state_dict()))
+    frames = torch.cat([heat, heat.flip(0)])[:4]             # a global batch of 4 distinct frames
+    lo, hi = D.shard_frames(frames.shape[0], world, rank)
+    gat = D.ResultGatherer(world)
+    with torch.no_grad():
+        fused = model(meta={"seq": [seq] * (hi - lo)}, input_heatmaps=frames[lo:hi].contiguous(), cameras=cams,
+                      resize_transform=rt)[0]
+        out = gat.gather(fused).clone()
+        gat.synchronize()
+        whole = model(meta={"seq": [seq] * frames.shape[0]}, input_heatmaps=frames, cameras=cams, resize_transform=rt)[0] \
+            if rank == 0 else None
+    dist.barrier()
+    if rank == 0:
+        q.put((out, whole))
+    dist.destroy_process_group()
+
+
+def test_sharded_real_hot_path_equals_single_process_bit_for_bit():
+    """SURVEY 8e on the real path: two gloo ranks each run the hot path (emulated kernels, miniature config) on their
+    contiguous shard of a 4-frame batch and all_gather the fused poses; the result equals one process running all four
+    frames, bit for bit (frames are independent units: nothing in the path mixes them)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker_real_path, args=(r, world, 29627, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, whole = q.get()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert out.shape == whole.shape and out.shape[0] == 4
+    assert torch.equal(out, whole)
+    assert bool((whole[..., 3] >= 0).any()), "the fixture must contain valid people"
