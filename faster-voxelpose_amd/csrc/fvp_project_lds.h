@@ -29,6 +29,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef FVP_TRI_PACKED
 #define FVP_TRI_PACKED 1
 #endif
+#ifndef FVP_TRI_EXPLICIT_AS
+#define FVP_TRI_EXPLICIT_AS 1   // 0: FLAT loads everywhere, 1: split by address space where it pays (NVL > 1), 2: everywhere
+#endif
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// 16-byte loads with the address space spelled out (a generic pointer would become a FLAT load)
+__device__ __forceinline__ float4 lds_ld4(const float* p) {
+  const f32x4v v = *(const __attribute__((address_space(3))) f32x4v*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 glb_ld4(const float* p) {
+  const f32x4v v = *(const __attribute__((address_space(1))) f32x4v*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 struct TapL {      // tap descriptor of one (voxel, view), relative to the staged rectangle
   int base;        // float offset of the nw tap's pixel (clamped into the rectangle), channel 0, in the LDS tile
@@ -290,17 +304,43 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
       if (t < 4) rect[4 * (v % 3) + t] = INT_MIN;                        // slot of view v (= view v+3): all its readers passed the barrier
       // ---- sample the thread's 8 voxels of view v (owner lane i & 3 holds the descriptor of voxel i)
       if (rcur.any && !(ablate & 1) && (rcur.lds || !(ablate & 8))) {   // (8: skip the global-gather fallback)
-        const float* src = rcur.big ? smem : (rcur.staged ? smem + (v & 1) * tile_sz : frame + size_t(v) * view_stride);
+        // Two pointers, one derived from the LDS array only and one global, and a uniform branch around the four tap
+        // loads: a single pointer selected at run time (rounds 1-2) forced FLAT loads, which take the texture-addresser
+        // path even when they land in LDS, plus a full vmcnt(0) wait per voxel - staging bought nothing (490 us with
+        // every rectangle gathered, 490 staged).  Only the loads are duplicated; duplicating the whole sampling code
+        // cost 37 spilled registers (645 us).
+        const bool from_lds = rcur.lds;
+        const float* lsrc = smem + ((rcur.big || !(v & 1)) ? 0 : tile_sz);
+        const float* gsrc = frame + size_t(v) * view_stride;
+        // NVL == 1 (JP = 16) keeps the single run-time pointer (FLAT loads): measured 490 us against 496 with the split
+        // loads (12 spilled registers); NVL == 2 gains from the split (Shelf 764 -> 674 us, no spills)
+        constexpr bool EXPLICIT_AS = (FVP_TRI_EXPLICIT_AS == 1) ? NVL > 1 : (FVP_TRI_EXPLICIT_AS > 1);
+        const float* src = from_lds ? lsrc : gsrc;
         auto sample = [&](const TapL& tv, float (&a)[NVL][4]) {
 #pragma unroll
           for (int n = 0; n < NVL; ++n) {
             const int ch0 = 16 * n + 4 * q;
             if (ch0 < JP) {
-              const float* p0 = src + tv.base + ch0;
-              const float4 v0 = *reinterpret_cast<const float4*>(p0);
-              const float4 v1 = *reinterpret_cast<const float4*>(p0 + tv.dx);
-              const float4 v2 = *reinterpret_cast<const float4*>(p0 + tv.dy);
-              const float4 v3 = *reinterpret_cast<const float4*>(p0 + tv.dy + tv.dx);
+              float4 v0, v1, v2, v3;
+              if constexpr (!EXPLICIT_AS) {
+                const float* p0 = src + tv.base + ch0;
+                v0 = *reinterpret_cast<const float4*>(p0);
+                v1 = *reinterpret_cast<const float4*>(p0 + tv.dx);
+                v2 = *reinterpret_cast<const float4*>(p0 + tv.dy);
+                v3 = *reinterpret_cast<const float4*>(p0 + tv.dy + tv.dx);
+              } else if (from_lds) {
+                const float* p0 = lsrc + tv.base + ch0;
+                v0 = lds_ld4(p0);
+                v1 = lds_ld4(p0 + tv.dx);
+                v2 = lds_ld4(p0 + tv.dy);
+                v3 = lds_ld4(p0 + tv.dy + tv.dx);
+              } else {
+                const float* p0 = gsrc + tv.base + ch0;
+                v0 = glb_ld4(p0);
+                v1 = glb_ld4(p0 + tv.dx);
+                v2 = glb_ld4(p0 + tv.dy);
+                v3 = glb_ld4(p0 + tv.dy + tv.dx);
+              }
 #if FVP_TRI_PACKED
               // packed fp32 on register pairs: IEEE per element, the same operation order per channel (same bits)
               const f32x2 w0 = f32x2{tv.w[0], tv.w[0]}, w1 = f32x2{tv.w[1], tv.w[1]}, w2 = f32x2{tv.w[2], tv.w[2]},
@@ -610,6 +650,8 @@ k_project_triplane_lds2(const float* __restrict__ heat_cl, const Cam* __restrict
       if (t < 4) rect[4 * (v % 3) + t] = INT_MIN;                        // slot of view v (= view v+3): all its readers passed the barrier
       if (rcur.any && !(ablate & 1) && (rcur.lds || !(ablate & 8))) {   // (8: skip the global-gather fallback)
         const float* src = rcur.big ? smem : (rcur.staged ? smem + (v & 1) * tile_sz : frame + size_t(v) * view_stride);
+        // (one run-time pointer = FLAT loads, unlike the quad form: with the loads split by address space the
+        //  scheduler hoists all 4 NQ of them per voxel in both copies and spills 160-255 registers - 2.7 ms on Shelf)
 #pragma unroll
         for (int k = 0; k < VPT; ++k) {
           const TapL d = finish(cur, k, rcur);
