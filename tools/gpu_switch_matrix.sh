@@ -1,0 +1,12 @@
+#!/usr/bin/env bash
+# GPU parity suite under the kernel-selection switches (every alternative form must pass the same tests)
+root="${GRAFT_REPO_ROOT:-$(pwd)}"; cd "$root"; export TMPDIR=/tmp
+run() { echo -n "$* : "; env "$@" timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -x 2>&1 | tail -1; }
+run X=1
+run FVP_TRIPLANE_QUAD=1
+run FVP_TRIPLANE_LANE=1 FVP_TRI_TWO_TILE=1
+run FVP_TRIPLANE_QUAD=1 FVP_TRI_TWO_TILE=1 FVP_TRI_CAP_PX=200
+run FVP_TRIPLANE_GATHER=1
+run FVP_CONV_NO_KSPLIT=1 FVP_CONV_NO_HEAD_FUSE=1 FVP_CONV_NO_POOL_FUSE=1
+run FVP_CONV_NO_WINO=1
+run FVP_WINO_HALF=1
