@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -71,6 +72,7 @@ struct ConvArgs {
   int wino_ni;        // Winograd: input DMA rounds (of 512 x 16 B) per chunk
   int nunits, ysplit; // Winograd: work units (plane group x row band x cout block), cout blocks
   unsigned m_ys, m_ty; // fdiv magics: ysplit, tiles_y
+  unsigned long long* dbg;   // Winograd, diagnostics build (-DFVP_WINO_TIMING=1): phase cycle sums
   float* pool_dst;    // Winograd: if set, max_pool(2,2) of the output is written here too (one value per 2x2 tile)
   int wrow;           // k_conv_dma: floats per packed weight row (coutp, or 2*coutp for the paired transposed conv)
   unsigned m_tpp, m_tpr;
@@ -1067,8 +1069,32 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   a.m_ty = make_magic(a.tiles_y);
   dim3 grid(std::min(a.nunits, persistent_workgroups() * (WC * WT == 4 ? 2 : 1)), 1, 1);
   ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
+#if FVP_WINO_TIMING
+  static unsigned long long* dbg = nullptr;
+  if (!dbg && hipMalloc(&dbg, 20 * sizeof(unsigned long long)) != hipSuccess) dbg = nullptr;
+  if (dbg) (void)hipMemsetAsync(dbg, 0, 20 * sizeof(unsigned long long), s);
+  a.dbg = dbg;
+  int rc = (WC * WT == 4) ? launch_wino<1, 4>(a, grid, lds, s, false)
+                          : (WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false));
+  if (dbg && getenv("FVP_WINO_TIMING_PRINT")) {
+    unsigned long long h[20];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    static const char* nm[8] = {"lgkm wait", "fetch+transform", "mfma16(0)", "lgkm wait 2", "vm wait+barrier+fetch", "mfma16(1)", "loop gap", "kernel total"};
+    fprintf(stderr, "[wino timing] %d->%d @%dx%d planes %d WC %d WT %d units %d grid %u\n", op.cin, op.cout, op.h, op.w, planes, WC, WT, a.nunits, grid.x);
+    for (int g = 0; g < 2; ++g) {
+      const unsigned long long* d = h + 10 * g;
+      if (!d[8]) continue;
+      fprintf(stderr, "   waves %s (%llu):", g ? "4-7" : "0-3", d[8]);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f |", nm[i], double(d[i]) / double(d[8]));
+      fprintf(stderr, "\n");
+    }
+  }
+  return rc;
+#else
   if (WC * WT == 4) return launch_wino<1, 4>(a, grid, lds, s, false);
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false);
+#endif
 }
 
 // ConvTranspose(k2,s2) in the paired form: CB = 2*coutp/32 accumulator blocks (both column taps),

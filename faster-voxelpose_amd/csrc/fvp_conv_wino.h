@@ -23,11 +23,50 @@
 #pragma once
 
 // cache policy of the input-tile DMA (aux bits of global_load_lds); nt (= 2) measured 1 % slower
+#ifndef FVP_WINO_TIMING
+#define FVP_WINO_TIMING 0
+#endif
+// Chunk barrier of the K loop.  __syncthreads() is a workgroup FENCE + barrier: the fence makes hipcc drain every
+// outstanding LDS-DMA (s_waitcnt vmcnt(0)) - including the chunk requested a moment ago - so the counted vmcnt in front
+// of it was dead code and the ring never had a chunk in flight across a barrier (found in the ISA in round 3).  The
+// plain s_barrier leaves the counters to the explicit waits: lgkmcnt(0) (this wave's reads of the slot are done) and
+// vmcnt(nps) (its items of chunk g+1 have landed; chunk g+2 stays in flight).
+#ifndef FVP_WINO_FENCE_BARRIER
+#define FVP_WINO_FENCE_BARRIER 0
+#endif
+#if FVP_WINO_FENCE_BARRIER
+#define FVP_WINO_BARRIER() __syncthreads()
+#else
+#define FVP_WINO_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#ifndef FVP_WINO_YOUNG_PRIO
+#define FVP_WINO_YOUNG_PRIO 0
+#endif
+#ifndef FVP_WINO_ASM_DMA
+#define FVP_WINO_ASM_DMA 1
+#endif
 #ifndef FVP_WINO_IN_AUX
 #define FVP_WINO_IN_AUX 0
 #endif
 
 namespace fvp {
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS at `l` (wave-uniform).
+// FVP_WINO_ASM_DMA: the instruction is emitted as inline asm.  With the builtin, hipcc knows that LDS is written behind
+// its back and puts a full `s_waitcnt vmcnt(0)` in front of the first LDS read that follows a pending DMA - i.e. at
+// the top of every chunk of the K loop, right after the chunk two ahead was requested: every chunk paid the whole
+// L2 -> LDS latency and the counted waits of the source were dead code (round 3, found in the ISA; the K loop compiled
+// without the DMA has no vmcnt wait at all).  As asm the DMA is invisible to the waitcnt pass; ordering is what the
+// source says: s_waitcnt vmcnt(n) counted per chunk + s_barrier.
+__device__ __forceinline__ void lds_dma16(const float* g, float* l, int aux) {
+#if FVP_WINO_ASM_DMA && !defined(HIPEMU)
+  const unsigned la = __builtin_amdgcn_readfirstlane(unsigned(size_t((__attribute__((address_space(3))) float*)l)));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory", "m0");
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0,
+                                   FVP_WINO_IN_AUX);
+#endif
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -84,6 +123,10 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   };
   int u = next_unit(blockIdx.x);
   if (u >= nunits) return;
+#if FVP_WINO_YOUNG_PRIO
+  // the second-dispatched half of an 8-wave workgroup loses the VALU arbitration on every segment (age): static priority
+  if (NWV == 8 && wave >= NWV / 2) __builtin_amdgcn_s_setprio(FVP_WINO_YOUNG_PRIO);
+#endif
 
   // this lane's 2x2 output tile inside the workgroup tile: TN planes x TR rows x tpr tiles; lanes beyond that
   // product (row lengths that do not divide 16*WT) compute on tile 0's data and store nothing
@@ -176,16 +219,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       if (j < a.wino_ni) {
         const int g = wave + NWV * j;
         const float* src = ((okmask >> j) & 1u) ? bk + rel_off[j] : a.zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, FVP_WINO_IN_AUX);
+        lds_dma16(src, xs + g * 256, FVP_WINO_IN_AUX);
       }
     }
     const float* wk = gwbase + size_t(k) * w_step + woff0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int g = wave + NWV * j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + j * wdj),
-                                       (__attribute__((address_space(3))) void*)(ws + g * 256), 16, 0, 0);
+      lds_dma16(wk + j * wdj, ws + g * 256, 0);
     }
   };
   enter_unit(su);
@@ -240,8 +281,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     const int rounds = (a.cinp * CBW * 4) / (NWV * 64);
     for (int j = 0; j < rounds; ++j) {
       const int g = wave + NWV * j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wts + size_t(g * 64 + lane) * 4),
-                                       (__attribute__((address_space(3))) void*)(smem + 4 + 3 * buf_sz + g * 256), 16, 0, 0);
+      lds_dma16(a.wts + size_t(g * 64 + lane) * 4, const_cast<float*>(smem) + 4 + 3 * buf_sz + g * 256, 0);
     }
     if (!dma) wait_vmcnt(0);
   }
@@ -251,6 +291,17 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     wait_vmcnt(second ? nps : 0);
   }
   __syncthreads();
+#if FVP_WINO_TIMING
+  // diagnostics build: s_memtime stamps around the phases of a step; the stamps are consumed right after the next
+  // lgkmcnt(0) wait of the loop itself, so they add no waits of their own
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tEE = 0, tF = 0, tG = 0;
+  bool tvalid = false;
+  const unsigned long long tstart = __builtin_readcyclecounter();
+#define FVP_TS(x) x = __builtin_readcyclecounter()
+#else
+#define FVP_TS(x)
+#endif
   int cur_off = 0;
   fetch_a(0, wchunk(smem + 4, 0), 0);
   fetch_d(smem + 4, 0, WP);
@@ -266,8 +317,21 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       // ---- half-step 0: patch transform, cout block 0
+#if FVP_WINO_TIMING
+      const unsigned long long tA2 = __builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): av[0] and the patch have landed
       __builtin_amdgcn_sched_barrier(0);
+#if FVP_WINO_TIMING
+      if (tvalid) {                                  // previous step: every stamp has returned (wait above)
+        tacc[0] += tB - tA; tacc[1] += tC - tB; tacc[2] += tD - tC; tacc[3] += tEE - tD; tacc[4] += tF - tEE;
+        tacc[5] += tG - tF; tacc[6] += tA2 - tG;
+      }
+      tvalid = true;
+      tA = tA2;
+      FVP_TS(tB);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       fetch_a(1, wchunk(cur, k), s);
       __builtin_amdgcn_sched_barrier(0);             // issue the reads now: left alone hipcc sinks them below the MFMAs
       f32x2 tM[4], tE[4];
@@ -276,26 +340,35 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) wino_cols(tE[xi], tM[xi], v03[xi], v12[xi]);
+#if FVP_WINO_TIMING
+      __builtin_amdgcn_sched_barrier(0);
+      FVP_TS(tC);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       mfma16(0);
       __builtin_amdgcn_sched_barrier(0);
+      FVP_TS(tD);
       // ---- half-step 1: cout block 1; the last one of a chunk crosses into the next slot
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_sched_barrier(0);
+      FVP_TS(tEE);
       if (s + 1 < S) {
         fetch_a(0, wchunk(cur, k), s + 1);
       } else {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
         // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
         if (dma) wait_vmcnt(more ? nps : 0);
-        __syncthreads();
+        FVP_WINO_BARRIER();
         if (k + 1 < nchunks) {                       // (a unit's last chunk: the epilogue needs the registers)
           fetch_a(0, wchunk(nxt, k + 1), 0);
           fetch_d(nxt, 0, wp);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      FVP_TS(tF);
       mfma16(1);
       __builtin_amdgcn_sched_barrier(0);
+      FVP_TS(tG);
     }
     cur_off = nxt_off;
   }
@@ -383,6 +456,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   fetch_a(0, wchunk(smem + 4 + cur_off, 0), 0);
   fetch_d(smem + 4 + cur_off, 0, WP);
   }
+#if FVP_WINO_TIMING
+  if (a.dbg && lane == 0) {
+    tacc[7] = __builtin_readcyclecounter() - tstart;
+    unsigned long long* d = a.dbg + (wave >= NWV / 2 ? 10 : 0);
+    for (int i = 0; i < 8; ++i) atomicAdd(d + i, tacc[i]);
+    atomicAdd(d + 8, 1ull);
+  }
+#endif
 }
 
 // state_dict weight [cout][cin][3][3] -> Winograd-domain U = G g G^T, layout [cinp][coutp][16]
