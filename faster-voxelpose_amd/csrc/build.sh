@@ -13,6 +13,7 @@ srcs=(fvp_capi.hip fvp_project.hip fvp_conv.hip fvp_conv1d_fused.hip fvp_proposa
 hdrs=("${here}"/*.h "${here}/../../include/fvp.h")
 objs=()
 compiled=0
+pids=()
 for s in "${srcs[@]}"; do
   o="${here}/${s%.hip}.o"
   stale=$force
@@ -26,11 +27,15 @@ for s in "${srcs[@]}"; do
     # file keeps the default.
     extra=(-ffp-contract=off)
     [[ "$s" == "fvp_conv.hip" ]] && extra=()
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" -c "${here}/$s" -o "$o" &
+    # (a failed compile must not leave the previous object behind to be linked)
+    ( "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" -c "${here}/$s" -o "$o.tmp" && mv "$o.tmp" "$o" || { rm -f "$o" "$o.tmp"; exit 1; } ) &
+    pids+=($!)
     compiled=$((compiled + 1))
   fi
   objs+=("$o")
 done
-wait
+for p in "${pids[@]:-}"; do
+  [[ -z "$p" ]] || wait "$p" || { echo "build.sh: a compile failed" >&2; exit 1; }
+done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
 echo "built $out (${compiled} of ${#srcs[@]} objects recompiled$([[ $force == 1 ]] && echo ', forced'))"

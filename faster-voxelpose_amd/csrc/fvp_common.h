@@ -18,22 +18,14 @@ __device__ __forceinline__ float bn_affine(float acc, float bias, float scale, f
   return __fmaf_rn(acc + bias, scale, shift);
 }
 
-// s_waitcnt vmcnt(n) with lgkmcnt / expcnt left alone (simm16: vmcnt[3:0] | expcnt 7<<4 | lgkmcnt 15<<8)
+// s_waitcnt vmcnt(n), n = 0..63, with lgkmcnt / expcnt left alone (gfx9 simm16: vmcnt[3:0] | expcnt 7<<4 | lgkmcnt 15<<8 |
+// vmcnt[5:4] << 14); n is wave-uniform, the switch compiles to a scalar jump
+#define FVP_VMCNT_CASE(n) case n: __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 15) | (((n) >> 4) << 14)); break;
+#define FVP_VMCNT_CASE4(n) FVP_VMCNT_CASE(n) FVP_VMCNT_CASE(n + 1) FVP_VMCNT_CASE(n + 2) FVP_VMCNT_CASE(n + 3)
+#define FVP_VMCNT_CASE16(n) FVP_VMCNT_CASE4(n) FVP_VMCNT_CASE4(n + 4) FVP_VMCNT_CASE4(n + 8) FVP_VMCNT_CASE4(n + 12)
 __device__ __forceinline__ void wait_vmcnt(int n) {
   switch (n) {
-    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
-    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
-    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
-    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
-    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
-    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
-    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
-    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
-    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
-    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
-    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
-    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
-    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
+    FVP_VMCNT_CASE16(0) FVP_VMCNT_CASE16(16) FVP_VMCNT_CASE16(32) FVP_VMCNT_CASE16(48)
     default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
   }
 }

@@ -1039,6 +1039,7 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   // resident weights: one 32-cout block covers all couts and [cinp][32][16] fits beside the three input slots
   const size_t resw_bytes = size_t(op.cinp) * CBW * 64;
   const size_t budget = WC * WT == 4 ? std::min<size_t>(kWinoLdsBudget, 78 * 1024) : kWinoLdsBudget;   // two workgroups per CU
+  const size_t epi_bytes = size_t(3) * op.coutp * 4;     // bias | scale | shift in LDS
   bool resw = WC == 1 && WT == 8 && op.coutp == 32 && op.cinp % 8 == 0 && resw_bytes <= 64 * 1024 && !kWinoNoResW;
   auto slot_bytes = [&](int cc, int* ni, bool rw) {
     const size_t quads = size_t(cc) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1;
@@ -1048,21 +1049,21 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   };
   int CC = op.cinp % 8 == 0 ? 8 : 4, ni = 0;
   size_t slot = slot_bytes(CC, &ni, resw);
-  if (resw && (3 * slot + resw_bytes + 64 > budget || ni > 4)) {
+  if (resw && (3 * slot + resw_bytes + 64 + epi_bytes > budget || ni > 4)) {
     resw = false;
     slot = slot_bytes(CC, &ni, false);
   }
-  if (CC == 8 && !resw && (3 * slot + 64 > budget || ni > 4)) {
+  if (CC == 8 && !resw && (3 * slot + 64 + epi_bytes > budget || ni > 4)) {
     CC = 4;
     slot = slot_bytes(CC, &ni, false);
   }
-  if (3 * slot + (resw ? resw_bytes : 0) + 64 > budget || ni > 4) return FVP_ELIMIT;
+  if (3 * slot + (resw ? resw_bytes : 0) + 64 + epi_bytes > budget || ni > 4) return FVP_ELIMIT;
   a.CC = CC;
   a.wino_ni = ni;
   a.m_qpr = make_magic(op.w / 4 + 1);
   a.m_rpc = make_magic(TN * (a.TH + 2));
   a.m_thp = make_magic(a.TH + 2);
-  const size_t lds = 16 + 3 * slot + (resw ? resw_bytes : 0);
+  const size_t lds = 16 + 3 * slot + (resw ? resw_bytes : 0) + epi_bytes;
   a.ysplit = op.coutp / CBW;
   a.nunits = a.tiles_y * ceil_div(planes, TN) * a.ysplit;
   a.m_ys = make_magic(a.ysplit);
@@ -1071,22 +1072,22 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
 #if FVP_WINO_TIMING
   static unsigned long long* dbg = nullptr;
-  if (!dbg && hipMalloc(&dbg, 20 * sizeof(unsigned long long)) != hipSuccess) dbg = nullptr;
-  if (dbg) (void)hipMemsetAsync(dbg, 0, 20 * sizeof(unsigned long long), s);
+  if (!dbg && hipMalloc(&dbg, 32 * sizeof(unsigned long long)) != hipSuccess) dbg = nullptr;
+  if (dbg) (void)hipMemsetAsync(dbg, 0, 32 * sizeof(unsigned long long), s);
   a.dbg = dbg;
   int rc = (WC * WT == 4) ? launch_wino<1, 4>(a, grid, lds, s, false)
                           : (WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false));
   if (dbg && getenv("FVP_WINO_TIMING_PRINT")) {
-    unsigned long long h[20];
+    unsigned long long h[32];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-    static const char* nm[8] = {"lgkm wait", "fetch+transform", "mfma16(0)", "lgkm wait 2", "vm wait+barrier+fetch", "mfma16(1)", "loop gap", "kernel total"};
+    static const char* nm[12] = {"lgkm wait", "fetch+transform", "mfma16(0)", "lgkm wait 2", "vm wait+barrier+fetch", "mfma16(1)", "loop gap", "kernel total", "vm wait", "barrier", "stage_next", "epilogue"};
     fprintf(stderr, "[wino timing] %d->%d @%dx%d planes %d WC %d WT %d units %d grid %u\n", op.cin, op.cout, op.h, op.w, planes, WC, WT, a.nunits, grid.x);
     for (int g = 0; g < 2; ++g) {
-      const unsigned long long* d = h + 10 * g;
-      if (!d[8]) continue;
-      fprintf(stderr, "   waves %s (%llu):", g ? "4-7" : "0-3", d[8]);
-      for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f |", nm[i], double(d[i]) / double(d[8]));
+      const unsigned long long* d = h + 16 * g;
+      if (!d[15]) continue;
+      fprintf(stderr, "   waves %s (%llu):", g ? "4-7" : "0-3", d[15]);
+      for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.0f |", nm[i], double(d[i]) / double(d[15]));
       fprintf(stderr, "\n");
     }
   }

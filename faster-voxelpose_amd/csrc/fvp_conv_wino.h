@@ -42,6 +42,13 @@
 #ifndef FVP_WINO_YOUNG_PRIO
 #define FVP_WINO_YOUNG_PRIO 0
 #endif
+#ifndef FVP_WINO_STORES_IN_FLIGHT
+#define FVP_WINO_STORES_IN_FLIGHT 1
+#endif
+// K-loop ablation switches (FVP_CONV_ABLATE bits 4, 64, 128, 256, 512) only exist in a diagnostics build
+#ifndef FVP_WINO_DIAG
+#define FVP_WINO_DIAG 0
+#endif
 #ifndef FVP_WINO_ASM_DMA
 #define FVP_WINO_ASM_DMA 1
 #endif
@@ -58,13 +65,16 @@ namespace fvp {
 // L2 -> LDS latency and the counted waits of the source were dead code (round 3, found in the ISA; the K loop compiled
 // without the DMA has no vmcnt wait at all).  As asm the DMA is invisible to the waitcnt pass; ordering is what the
 // source says: s_waitcnt vmcnt(n) counted per chunk + s_barrier.
-__device__ __forceinline__ void lds_dma16(const float* g, float* l, int aux) {
+// The LDS destination is given as (array, float index): the generic -> LDS cast of the bare array folds to a constant; a
+// cast of a pointer VARIABLE makes hipcc emit a null check that this compiler version mis-selects ("Illegal instruction").
+__device__ __forceinline__ void lds_dma16(const float* g, const float* lds, int idx, int aux) {
 #if FVP_WINO_ASM_DMA && !defined(HIPEMU)
-  const unsigned la = __builtin_amdgcn_readfirstlane(unsigned(size_t((__attribute__((address_space(3))) float*)l)));
+  const unsigned base = unsigned(size_t((const __attribute__((address_space(3))) float*)lds));
+  const unsigned la = __builtin_amdgcn_readfirstlane(base + 4u * unsigned(idx));
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory", "m0");
 #else
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0,
-                                   FVP_WINO_IN_AUX);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)(const_cast<float*>(lds) + idx), 16, 0, FVP_WINO_IN_AUX);
 #endif
 }
 
@@ -211,41 +221,42 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   const size_t wdj = size_t(DCI) * a.coutp * 16;
   // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
   auto stage = [&](int k, int boff) {
-    float* xs = smem + 4 + boff;
-    float* ws = xs + xs_sz;
     const float* bk = ubase + size_t(k) * in_step;
 #pragma unroll
     for (int j = 0; j < kMaxIn; ++j) {
       if (j < a.wino_ni) {
         const int g = wave + NWV * j;
         const float* src = ((okmask >> j) & 1u) ? bk + rel_off[j] : a.zeros;
-        lds_dma16(src, xs + g * 256, FVP_WINO_IN_AUX);
+        lds_dma16(src, smem, 4 + boff + g * 256, FVP_WINO_IN_AUX);
       }
     }
     const float* wk = gwbase + size_t(k) * w_step + woff0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int g = wave + NWV * j;
-      lds_dma16(wk + j * wdj, ws + g * 256, 0);
+      lds_dma16(wk + j * wdj, smem, 4 + boff + xs_sz + g * 256, 0);
     }
   };
   enter_unit(su);
-  auto stage_next = [&](int boff) {
-    if (su >= nunits) return false;
-    stage(sk, boff);
+  auto advance_cursor = [&]() {
     if (++sk == nchunks) {
       sk = 0;
       su = next_unit(su + G);
       if (su < nunits) enter_unit(su);
     }
+  };
+  auto stage_next = [&](int boff) {
+    if (su >= nunits) return false;
+    stage(sk, boff);
+    advance_cursor();
     return true;
   };
-
   // ---- operand fetch / transform / MFMA building blocks
   float4 av[2][4];
   f32x2 dM[4], dE[4];                                // patch rows as pairs (d1,d2) and (d0,d3)
   f32x2 v03[4], v12[4];                              // V[xi][0],V[xi][3] and V[xi][1],V[xi][2]
   auto fetch_a = [&](int cb, const float* wbase, int s) {     // wbase = weights of the chunk, s = step in chunk
+    if (FVP_WINO_DIAG && (a.ablate & 256)) return;                      // diagnostics: no A-operand reads
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi)
       av[cb][xi] = *reinterpret_cast<const float4*>(wbase + aoff[xi] + (s * 4 * CBW * 16 + cb * 256));
@@ -256,7 +267,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     for (int r = 0; r < 4; ++r) {
       const float* row = xs + r * wp;
       dM[r] = *reinterpret_cast<const f32x2*>(row + 1);       // 8-byte aligned: column 4 + 2*tx
-      dE[r] = f32x2{row[0], row[3]};
+      dE[r] = (FVP_WINO_DIAG && (a.ablate & 64)) ? dM[r] : f32x2{row[0], row[3]};   // (bit 64, diagnostics: no single-float patch reads)
     }
   };
   auto transform_rows = [&](f32x2 (&tM)[4], f32x2 (&tE)[4]) {  // B^T d
@@ -266,6 +277,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     tM[3] = dM[1] - dM[3];  tE[3] = dE[1] - dE[3];
   };
   auto mfma16 = [&](int cb) {
+    if (FVP_WINO_DIAG && (a.ablate & 4)) return;                        // diagnostics: no MFMA
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) {
       acc[cb][4 * xi + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].x, v03[xi].x, acc[cb][4 * xi + 0], 0, 0, 0);
@@ -281,9 +293,16 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     const int rounds = (a.cinp * CBW * 4) / (NWV * 64);
     for (int j = 0; j < rounds; ++j) {
       const int g = wave + NWV * j;
-      lds_dma16(a.wts + size_t(g * 64 + lane) * 4, const_cast<float*>(smem) + 4 + 3 * buf_sz + g * 256, 0);
+      lds_dma16(a.wts + size_t(g * 64 + lane) * 4, smem, 4 + 3 * buf_sz + g * 256, 0);
     }
     if (!dma) wait_vmcnt(0);
+  }
+  // bias | scale | shift of every cout, [3][coutp], behind the slots (and the resident weights): the epilogue reads them
+  // with ds_read (lgkmcnt).  As global loads they sat in the in-order vmcnt queue behind the previous cout's stores, and
+  // every one of the 8 couts of a lane paid a store round trip plus a load round trip (round 3, found in the ISA).
+  {
+    float* const e = const_cast<float*>(smem) + 4 + 3 * buf_sz + (RESW ? a.cinp * CBW * 16 : 0);
+    for (int i = t; i < 3 * a.coutp; i += NWV * 64) e[i] = a.epi[i];
   }
   if (dma) {
     stage_next(0);
@@ -294,7 +313,8 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
 #if FVP_WINO_TIMING
   // diagnostics build: s_memtime stamps around the phases of a step; the stamps are consumed right after the next
   // lgkmcnt(0) wait of the loop itself, so they add no waits of their own
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tV = 0, tBar = 0;
   unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tEE = 0, tF = 0, tG = 0;
   bool tvalid = false;
   const unsigned long long tstart = __builtin_readcyclecounter();
@@ -303,13 +323,24 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
 #define FVP_TS(x)
 #endif
   int cur_off = 0;
+  int st_pending = 0;                                // stores of the previous unit's epilogue that may still be in flight
   fetch_a(0, wchunk(smem + 4, 0), 0);
   fetch_d(smem + 4, 0, WP);
   while (true) {
   for (int k = 0; k < nchunks; ++k) {
     const int nxt_off = cur_off + buf_sz >= 3 * buf_sz ? 0 : cur_off + buf_sz;
     const int nn_off = nxt_off + buf_sz >= 3 * buf_sz ? 0 : nxt_off + buf_sz;
+#if FVP_WINO_TIMING
+    const unsigned long long tS0 = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const bool more = dma && stage_next(nn_off);
+#if FVP_WINO_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long tS1 = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    tacc[10] += tS1 - tS0;
+#endif
     const float* cur = smem + 4 + cur_off;
     const float* nxt = smem + 4 + nxt_off;
     int wp = WP;
@@ -335,11 +366,19 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       fetch_a(1, wchunk(cur, k), s);
       __builtin_amdgcn_sched_barrier(0);             // issue the reads now: left alone hipcc sinks them below the MFMAs
       f32x2 tM[4], tE[4];
-      transform_rows(tM, tE);
+      if (FVP_WINO_DIAG && (a.ablate & 512)) {                          // diagnostics: no input transform
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { tM[r] = dM[r]; tE[r] = dE[r]; }
+      } else {
+        transform_rows(tM, tE);
+      }
       if (s + 1 < S) fetch_d(cur, s + 1, wp);        // the patch registers are dead: refill for the next step
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int xi = 0; xi < 4; ++xi) wino_cols(tE[xi], tM[xi], v03[xi], v12[xi]);
+      for (int xi = 0; xi < 4; ++xi) {
+        if (FVP_WINO_DIAG && (a.ablate & 512)) { v03[xi] = tE[xi]; v12[xi] = tM[xi]; }
+        else wino_cols(tE[xi], tM[xi], v03[xi], v12[xi]);
+      }
 #if FVP_WINO_TIMING
       __builtin_amdgcn_sched_barrier(0);
       FVP_TS(tC);
@@ -357,8 +396,25 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       } else {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
         // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
-        if (dma) wait_vmcnt(more ? nps : 0);
-        FVP_WINO_BARRIER();
+        if (dma) {
+          const int keep = (more ? nps : 0) + st_pending;
+          wait_vmcnt(keep < 63 ? keep : 63);
+          st_pending = 0;
+        }
+#if FVP_WINO_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        tV = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (!(FVP_WINO_DIAG && (a.ablate & 128))) FVP_WINO_BARRIER();     // (bit 128, diagnostics: no chunk barrier)
+#if FVP_WINO_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        tBar = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_sched_barrier(0);
+        tacc[8] += tV - tEE; tacc[9] += tBar - tV;
+#endif
         if (k + 1 < nchunks) {                       // (a unit's last chunk: the epilogue needs the registers)
           fetch_a(0, wchunk(nxt, k + 1), 0);
           fetch_d(nxt, 0, wp);
@@ -374,6 +430,10 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   }
 
   // ---- unit finished: output transform + epilogue, then the next unit of this workgroup
+#if FVP_WINO_TIMING
+  const unsigned long long tE0 = __builtin_readcyclecounter();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   int ue = u;
   FVP_OPAQUE(ue);                                    // keeps the epilogue's address math out of the K loop's live set
   const int ut = fdiv(ue, a.m_ys), uy = ue - ut * a.ysplit;
@@ -381,9 +441,6 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   const int plane0 = pg * a.TN, y0 = ty_i * a.TH, co0 = uy * CBW;
   if (!(a.ablate & 8)) {
   // per lane: tile (plane, y, x), 8 couts
-  const float* bias = a.epi;
-  const float* scale = a.epi + a.coutp;
-  const float* shift = a.epi + 2 * a.coutp;
   const bool relu = a.flags & FVP_EPI_RELU;
   const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
   const int plane = plane0 + tn, y = y0 + 2 * ty, x = 2 * tx;
@@ -391,22 +448,36 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   const unsigned pix = tile_ok ? unsigned(y * W + x) : 0u;
   const unsigned cbase = tile_ok ? unsigned(plane) * a.cout : 0u;
   const unsigned ppix = unsigned((y >> 1) * (W >> 1) + tx);
+  // vmcnt is in-order and counts stores: a load issued behind a store waits for the store's whole round trip, and the
+  // compiler may not move loads above stores itself (dst and res are not known to be distinct).  So every residual load
+  // of the lane (2 cout blocks x 4 couts x 2 rows) is issued before the first store.
+  int bs = buf_sz;
+  FVP_OPAQUE(bs);
+  const float* const epi_s = smem + 4 + 3 * bs + (RESW ? a.cinp * CBW * 16 : 0);
+  // element offset of (cout co4 + r, this lane's tile); padded couts and masked tiles read a valid address and store nothing
+  const unsigned omask = (a.ablate & 1024) ? 0x3ffffu : ~0u;   // (bit 1024, diagnostics: epilogue traffic stays inside 1 MB)
+  auto out_off = [&](int co) { return ((cbase + (tile_ok && co < a.cout ? co : 0)) * unsigned(HW) + pix) & omask; };
+  float2 r0[2][4], r1[2][4];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
-    unsigned off[4];
-    bool ok[4];
-    int co[4];
-    float2 r0[4], r1[4];
+    const int co4 = co0 + wc * 32 + cb * 16 + 4 * k4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      co[r] = co0 + wc * 32 + cb * 16 + 4 * k4 + r;
-      ok[r] = tile_ok && co[r] < a.cout;
-      off[r] = (cbase + (ok[r] ? co[r] : 0)) * unsigned(HW) + pix;
+      const unsigned off = out_off(co4 + r);
       if (HAS_RES) {
-        r0[r] = *reinterpret_cast<const float2*>(a.res + off[r]);
-        r1[r] = *reinterpret_cast<const float2*>(a.res + off[r] + W);
+        if (a.ablate & 16) {                         // diagnostics: no residual loads
+          r0[cb][r] = r1[cb][r] = make_float2(0.f, 0.f);
+        } else {
+          r0[cb][r] = *reinterpret_cast<const float2*>(a.res + off);
+          r1[cb][r] = *reinterpret_cast<const float2*>(a.res + off + W);
+        }
       }
     }
+  }
+  // output transform A^T M A of the 8 couts while the residual loads are in flight (the accumulators die here)
+  float o[2][4][2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float s[4][2];
@@ -417,33 +488,52 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         s[xi][0] = (m0 + m1) + m2;
         s[xi][1] = (m1 - m2) - m3;
       }
-      float o[2][2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        o[0][e] = (s[0][e] + s[1][e]) + s[2][e];
-        o[1][e] = (s[1][e] - s[2][e]) - s[3][e];
+        o[cb][r][0][e] = (s[0][e] + s[1][e]) + s[2][e];
+        o[cb][r][1][e] = (s[1][e] - s[2][e]) - s[3][e];
       }
-      const float b = bias[co[r]], sc = scale[co[r]], sh = shift[co[r]];
-      const float rr[2][2] = {{HAS_RES ? r0[r].x : 0.f, HAS_RES ? r0[r].y : 0.f},
-                              {HAS_RES ? r1[r].x : 0.f, HAS_RES ? r1[r].y : 0.f}};
+    }
+  // ONE wait for all residual loads.  The stores below are conditional (masked tiles), so behind the first of them the
+  // compiler's counter no longer knows how many younger operations are in the queue and every later use of a loaded
+  // value would get a full vmcnt(0) - i.e. wait for the stores issued so far.
+  __builtin_amdgcn_sched_barrier(0);
+  if (HAS_RES) wait_vmcnt(0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int co4 = co0 + wc * 32 + cb * 16 + 4 * k4;
+    f32x4 bn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bn[i] = *reinterpret_cast<const f32x4*>(epi_s + i * a.coutp + co4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b = bn[0][r], sc = bn[1][r], sh = bn[2][r];
+      const float rr[2][2] = {{HAS_RES ? r0[cb][r].x : 0.f, HAS_RES ? r0[cb][r].y : 0.f},
+                              {HAS_RES ? r1[cb][r].x : 0.f, HAS_RES ? r1[cb][r].y : 0.f}};
+      float v[2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          float v = bn_affine(o[i][e], b, sc, sh);
-          if (HAS_RES && !res_after) v += rr[i][e];
-          if (relu) v = fmaxf(v, 0.0f);
-          if (HAS_RES && res_after) v += rr[i][e];
-          o[i][e] = v;
+          float x = bn_affine(o[cb][r][i][e], b, sc, sh);
+          if (HAS_RES && !res_after) x += rr[i][e];
+          if (relu) x = fmaxf(x, 0.0f);
+          if (HAS_RES && res_after) x += rr[i][e];
+          v[i][e] = x;
         }
-      if (ok[r]) {
-        *reinterpret_cast<float2*>(a.dst + off[r]) = make_float2(o[0][0], o[0][1]);
-        *reinterpret_cast<float2*>(a.dst + off[r] + W) = make_float2(o[1][0], o[1][1]);
+      if (tile_ok && co4 + r < a.cout && (!(a.ablate & 32) || v[0][0] == 1.2345e-30f)) {   // (bit 32, diagnostics: no stores)
+        const unsigned off = out_off(co4 + r);
+        *reinterpret_cast<float2*>(a.dst + off) = make_float2(v[0][0], v[0][1]);
+        *reinterpret_cast<float2*>(a.dst + off + W) = make_float2(v[1][0], v[1][1]);
         if (a.pool_dst)                              // fused max_pool(2,2): this lane's tile is one pooled pixel
-          a.pool_dst[(cbase + co[r]) * unsigned(HW >> 2) + ppix] = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
+          a.pool_dst[(cbase + co4 + r) * unsigned(HW >> 2) + ppix] = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
       }
     }
   }
+  // the stores above sit in the (in-order) vmcnt queue BEHIND chunk 1 of the next unit, which was requested before them:
+  // the first chunk barrier of the next unit lets them stay in flight instead of waiting for their round trip
+  st_pending = FVP_WINO_STORES_IN_FLIGHT ? 16 + (a.pool_dst ? 8 : 0) : 0;
   }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
@@ -451,6 +541,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     for (int p = 0; p < 16; ++p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[cb][p][r] = 0.0f;
+#if FVP_WINO_TIMING
+  {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long tE1 = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    tacc[11] += tE1 - tE0;
+  }
+#endif
   u = next_unit(u + G);
   if (u >= nunits) break;
   fetch_a(0, wchunk(smem + 4 + cur_off, 0), 0);
@@ -459,9 +557,9 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
 #if FVP_WINO_TIMING
   if (a.dbg && lane == 0) {
     tacc[7] = __builtin_readcyclecounter() - tstart;
-    unsigned long long* d = a.dbg + (wave >= NWV / 2 ? 10 : 0);
-    for (int i = 0; i < 8; ++i) atomicAdd(d + i, tacc[i]);
-    atomicAdd(d + 8, 1ull);
+    unsigned long long* d = a.dbg + (wave >= NWV / 2 ? 16 : 0);
+    for (int i = 0; i < 15; ++i) atomicAdd(d + i, tacc[i]);
+    atomicAdd(d + 15, 1ull);
   }
 #endif
 }
