@@ -27,6 +27,16 @@
 
 #include "fvp_common.h"
 
+// ring slots of the LDS-DMA kernel's 128-cout configurations (chunks in flight = slots - 1).  Measured on the MI355X
+// (40 images, round 3, with the plain chunk barrier): 32-wide chunks 2 -> 3 slots (72 KB, still inside the epilogue's
+// 73.7 KB: two workgroups per CU) K-heavy 1x1 layers -5 %, pass 9.04 -> 8.93 ms; four slots (96 KB: one workgroup per
+// CU) 9.35 ms; 64-wide chunks with three slots (144 KB) cost the big transposed conv 7 %: two.
+#ifndef FVP_BB_SLOTS_128_64
+#define FVP_BB_SLOTS_128_64 2
+#endif
+#ifndef FVP_BB_SLOTS_128_32
+#define FVP_BB_SLOTS_128_32 3
+#endif
 #ifndef FVP_BB_NBUF
 #define FVP_BB_NBUF 1
 #endif
@@ -420,7 +430,11 @@ __global__ void __launch_bounds__(512, BN == 128 ? 4 : 2) k_bb_conv_dma(BbConvAr
   for (int c = 0; c < nchunks; ++c) {
     const int ahead = nchunks - 1 - c;                // chunks issued after c (at most D - 1 before this iteration's stage)
     wait_vmcnt((ahead < D - 1 ? ahead : D - 1) * LPC);  // this wave's share of chunk c has landed
-    __syncthreads();                                  // ... everybody's; and everybody is done reading chunk c - 1
+    // ... everybody's; and everybody is done reading chunk c - 1.  A plain s_barrier behind this wave's lgkmcnt(0):
+    // __syncthreads() is fence + barrier, and the fence drains EVERY outstanding LDS-DMA (vmcnt(0)), i.e. the chunks
+    // requested for later iterations too - with it a ring deeper than two slots never had more than one chunk in flight
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
     if (c + D < nchunks) stage(c + D);                // into the slot of chunk c - 1
     const char* S = smem + (c % NSLOT) * SLOTB;
 #pragma unroll
@@ -808,7 +822,8 @@ static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const 
     if (cfg == 1 && op.coutp % 256 != 0) cfg = 0;
     if (cfg == 0) cfg = bn == 256 ? 1 : 2;
     return cfg == 1 ? bb_launch_dma<256, 64, 2>(a, M, s, zeros)
-                    : cfg == 2 ? bb_launch_dma<128, 64, 2>(a, M, s, zeros) : bb_launch_dma<128, 32, 2>(a, M, s, zeros);
+                    : cfg == 2 ? bb_launch_dma<128, 64, FVP_BB_SLOTS_128_64>(a, M, s, zeros)
+                               : bb_launch_dma<128, 32, FVP_BB_SLOTS_128_32>(a, M, s, zeros);
   }
   const bool wide = op.coutp % 128 == 0;
   dim3 grid(ceil_div(M, 128), op.coutp / (wide ? 128 : 64), a.ncls);

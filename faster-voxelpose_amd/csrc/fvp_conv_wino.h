@@ -49,6 +49,9 @@
 #ifndef FVP_WINO_DIAG
 #define FVP_WINO_DIAG 0
 #endif
+#ifndef FVP_WINO_EPI_FAST
+#define FVP_WINO_EPI_FAST 1
+#endif
 #ifndef FVP_WINO_ASM_DMA
 #define FVP_WINO_ASM_DMA 1
 #endif
@@ -500,37 +503,44 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   if (HAS_RES) wait_vmcnt(0);
   __builtin_amdgcn_sched_barrier(0);
+  // every P2PNet / CenterNet layer on this kernel is BN (+ residual) -> ReLU: that order gets its own copy of the loop (as
+  // run-time flags the two selects per value were a quarter of the epilogue's instructions)
+  auto finalize = [&](auto fast) {
+    constexpr bool kFast = decltype(fast)::value;
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int co4 = co0 + wc * 32 + cb * 16 + 4 * k4;
-    f32x4 bn[3];
+    for (int cb = 0; cb < 2; ++cb) {
+      const int co4 = co0 + wc * 32 + cb * 16 + 4 * k4;
+      f32x4 bn[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) bn[i] = *reinterpret_cast<const f32x4*>(epi_s + i * a.coutp + co4);
+      for (int i = 0; i < 3; ++i) bn[i] = *reinterpret_cast<const f32x4*>(epi_s + i * a.coutp + co4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float b = bn[0][r], sc = bn[1][r], sh = bn[2][r];
-      const float rr[2][2] = {{HAS_RES ? r0[cb][r].x : 0.f, HAS_RES ? r0[cb][r].y : 0.f},
-                              {HAS_RES ? r1[cb][r].x : 0.f, HAS_RES ? r1[cb][r].y : 0.f}};
-      float v[2][2];
+      for (int r = 0; r < 4; ++r) {
+        const float b = bn[0][r], sc = bn[1][r], sh = bn[2][r];
+        const float rr[2][2] = {{HAS_RES ? r0[cb][r].x : 0.f, HAS_RES ? r0[cb][r].y : 0.f},
+                                {HAS_RES ? r1[cb][r].x : 0.f, HAS_RES ? r1[cb][r].y : 0.f}};
+        float v[2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          float x = bn_affine(o[cb][r][i][e], b, sc, sh);
-          if (HAS_RES && !res_after) x += rr[i][e];
-          if (relu) x = fmaxf(x, 0.0f);
-          if (HAS_RES && res_after) x += rr[i][e];
-          v[i][e] = x;
+          for (int e = 0; e < 2; ++e) {
+            float x = bn_affine(o[cb][r][i][e], b, sc, sh);
+            if (HAS_RES && (kFast || !res_after)) x += rr[i][e];
+            if (kFast || relu) x = fmaxf(x, 0.0f);
+            if (HAS_RES && !kFast && res_after) x += rr[i][e];
+            v[i][e] = x;
+          }
+        if (tile_ok && co4 + r < a.cout && (!(a.ablate & 32) || v[0][0] == 1.2345e-30f)) {   // (bit 32, diagnostics: no stores)
+          const unsigned off = out_off(co4 + r);
+          *reinterpret_cast<float2*>(a.dst + off) = make_float2(v[0][0], v[0][1]);
+          *reinterpret_cast<float2*>(a.dst + off + W) = make_float2(v[1][0], v[1][1]);
+          if (a.pool_dst)                              // fused max_pool(2,2): this lane's tile is one pooled pixel
+            a.pool_dst[(cbase + co4 + r) * unsigned(HW >> 2) + ppix] = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
         }
-      if (tile_ok && co4 + r < a.cout && (!(a.ablate & 32) || v[0][0] == 1.2345e-30f)) {   // (bit 32, diagnostics: no stores)
-        const unsigned off = out_off(co4 + r);
-        *reinterpret_cast<float2*>(a.dst + off) = make_float2(v[0][0], v[0][1]);
-        *reinterpret_cast<float2*>(a.dst + off + W) = make_float2(v[1][0], v[1][1]);
-        if (a.pool_dst)                              // fused max_pool(2,2): this lane's tile is one pooled pixel
-          a.pool_dst[(cbase + co4 + r) * unsigned(HW >> 2) + ppix] = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
       }
     }
-  }
+  };
+  if (FVP_WINO_EPI_FAST && relu && !res_after) finalize(std::integral_constant<bool, true>{});
+  else finalize(std::integral_constant<bool, false>{});
   // the stores above sit in the (in-order) vmcnt queue BEHIND chunk 1 of the next unit, which was requested before them:
   // the first chunk barrier of the next unit lets them stay in flight instead of waiting for their round trip
   st_pending = FVP_WINO_STORES_IN_FLIGHT ? 16 + (a.pool_dst ? 8 : 0) : 0;
