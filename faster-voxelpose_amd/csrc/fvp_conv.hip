@@ -82,6 +82,7 @@ struct ConvArgs {
   const float* epi2;  // its bias | scale | shift
   float* dst2;        // its output [planes][cout2][OH][OW]
   int cout2, flags2;
+  int epi_off;        // k_conv_dma: float offset of the BN vectors' copy in dynamic LDS (behind slots and epilogue scratch)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -89,11 +90,11 @@ struct ConvArgs {
 // are fetched with unconditional (address-clamped) loads, 16 per accumulator tile, before any
 // arithmetic, so they cost one memory latency per tile instead of one per element.
 template <int CB, int PB, bool HAS_RES>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[CB][PB], int wave, int l31, int half,
-                                              int plane0, int y0, int x0, int co0, int tapT) {
-  const float* bias = a.epi;
-  const float* scale = a.epi + a.coutp;
-  const float* shift = a.epi + 2 * a.coutp;
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const float* epi, f32x16 (&acc)[CB][PB], int wave, int l31,
+                                              int half, int plane0, int y0, int x0, int co0, int tapT) {
+  const float* bias = epi;
+  const float* scale = epi + a.coutp;
+  const float* shift = epi + 2 * a.coutp;
   const int OHW = a.OH * a.OW;
   const int dy = (a.ntapT > 1) ? tapT / a.tapT_w : 0, dx = (a.ntapT > 1) ? tapT % a.tapT_w : 0;
   const bool relu = a.flags & FVP_EPI_RELU;
@@ -309,19 +310,19 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
 
   if (a.ablate & 8) return;
   if (a.flags & FVP_EPI_RES)
-    conv_epilogue<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, x0, co0, tapT);
+    conv_epilogue<CB, PB, true>(a, a.epi, acc, wave, l31, half, plane0, y0, x0, co0, tapT);
   else
-    conv_epilogue<CB, PB, false>(a, acc, wave, l31, half, plane0, y0, x0, co0, tapT);
+    conv_epilogue<CB, PB, false>(a, a.epi, acc, wave, l31, half, plane0, y0, x0, co0, tapT);
 }
 
 // Epilogue of the PAIR layout: accumulator rows co / 16+co of a lane are pixels 2j / 2j+1 of the
 // same cout -> one float2 store per cout, 256 contiguous bytes per 32 lanes.
 template <int PB, bool HAS_RES>
-__device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x16 (&acc)[PB], int wave, int l31, int half,
-                                                   int plane0, int y0) {
-  const float* bias = a.epi;
-  const float* scale = a.epi + a.coutp;
-  const float* shift = a.epi + 2 * a.coutp;
+__device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, const float* epi, f32x16 (&acc)[PB], int wave, int l31,
+                                                   int half, int plane0, int y0) {
+  const float* bias = epi;
+  const float* scale = epi + a.coutp;
+  const float* shift = epi + 2 * a.coutp;
   const bool relu = a.flags & FVP_EPI_RELU;
   const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
   const int Wq = a.W >> 1;
@@ -375,13 +376,14 @@ __device__ __forceinline__ float hop32(float v, int from_upper) {
 
 // Epilogue of the paired transposed conv: blocks cb / cb + CB/2 are output columns 2x / 2x+1.
 template <int CB, int PB, bool HAS_RES, bool FUSE2 = false>
-__device__ __forceinline__ void conv_epilogue_tpair(const ConvArgs& a, f32x16 (&acc)[CB][PB], int wave, int l31,
-                                                    int half, int plane0, int y0, int dy, const float* w2s = nullptr) {
+__device__ __forceinline__ void conv_epilogue_tpair(const ConvArgs& a, const float* epi, f32x16 (&acc)[CB][PB], int wave, int l31,
+                                                    int half, int plane0, int y0, int dy, const float* w2s = nullptr,
+                                                    const float* epi2 = nullptr) {
   constexpr int CH = CB / 2;
   static_assert(!FUSE2 || CH == 1, "the fused 1x1 conv needs all 32 couts of a pixel in one lane pair");
-  const float* bias = a.epi;
-  const float* scale = a.epi + a.coutp;
-  const float* shift = a.epi + 2 * a.coutp;
+  const float* bias = epi;
+  const float* scale = epi + a.coutp;
+  const float* shift = epi + 2 * a.coutp;
   const bool relu = a.flags & FVP_EPI_RELU;
   const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
   const int tile_px = a.TN * a.TH * a.W;
@@ -432,9 +434,9 @@ __device__ __forceinline__ void conv_epilogue_tpair(const ConvArgs& a, f32x16 (&
     if (FUSE2) {
       // out[j] = sum_c W2[c][j] * y[c] for this lane's two pixels: a lane holds 16 of the 32 channels (channel
       // (r&3) + 8(r>>2) + 4 half in register r), its partner lane ^ 32 the other 16; W2 sits in LDS as [c][32]
-      const float* bias2 = a.epi2;
-      const float* scale2 = a.epi2 + 32;
-      const float* shift2 = a.epi2 + 64;
+      const float* bias2 = epi2;
+      const float* scale2 = epi2 + 32;
+      const float* shift2 = epi2 + 64;
       const bool relu2 = a.flags2 & FVP_EPI_RELU;
       const unsigned pb2 = pix_ok ? unsigned(plane) * a.cout2 : 0u;
 #pragma unroll
@@ -489,11 +491,11 @@ __device__ __forceinline__ void conv_epilogue_tpair(const ConvArgs& a, f32x16 (&
 // channel -> dwordx4 residual loads and dwordx4 stores in 128-byte runs (the MFMA layout gives a
 // lane 16 different channels of ONE pixel, i.e. 4-byte stores).
 template <int CB, int PB, bool HAS_RES>
-__device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, f32x16 (&acc)[CB][PB], float* scratch, int wave,
-                                                   int lane, int plane0, int y0, int co0) {
-  const float* bias = a.epi;
-  const float* scale = a.epi + a.coutp;
-  const float* shift = a.epi + 2 * a.coutp;
+__device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, const float* epi, f32x16 (&acc)[CB][PB], float* scratch,
+                                                   int wave, int lane, int plane0, int y0, int co0) {
+  const float* bias = epi;
+  const float* scale = epi + a.coutp;
+  const float* shift = epi + 2 * a.coutp;
   const bool relu = a.flags & FVP_EPI_RELU;
   const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
   const int tile_px = a.TN * a.TH * a.TW;
@@ -676,6 +678,16 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
     }
   };
 
+  // bias | scale | shift of every cout (+ the fused 1x1 conv's three 32-vectors) staged behind everything else in LDS: the
+  // epilogues read them with ds_read.  As global loads they queued behind the previous element's stores in the in-order
+  // vmcnt counter, and behind a conditional store the compiler can only wait with vmcnt(0): every output element of a
+  // lane paid a store round trip plus a load round trip (16-32 chained round trips per wave; round 3, found in the ISA)
+  const float* const epi_s = smem + a.epi_off;
+  {
+    float* e = smem + a.epi_off;
+    for (int i = t; i < 3 * a.coutp; i += 256) e[i] = a.epi[i];
+    if (TPAIR && a.w2 && t < 96) e[3 * a.coutp + t] = a.epi2[t];
+  }
   if (!(a.ablate & 3)) stage(0, 0);
   __syncthreads();
   for (int k = 0; k < nchunks; ++k) {
@@ -763,16 +775,16 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[cb][pb][r] += red[((((w - 1) * CB + cb) * PB + pb) * 16 + r) * 64 + lane];
     if (a.flags & FVP_EPI_RES)
-      conv_epilogue<CB, PB, true>(a, acc, 0, l31, half, plane0, y0, 0, co0, tapT);
+      conv_epilogue<CB, PB, true>(a, epi_s, acc, 0, l31, half, plane0, y0, 0, co0, tapT);
     else
-      conv_epilogue<CB, PB, false>(a, acc, 0, l31, half, plane0, y0, 0, co0, tapT);
+      conv_epilogue<CB, PB, false>(a, epi_s, acc, 0, l31, half, plane0, y0, 0, co0, tapT);
     return;
   }
   if (PAIR) {
     if (a.flags & FVP_EPI_RES)
-      conv_epilogue_pair<PB, true>(a, acc[0], wave, l31, half, plane0, y0);
+      conv_epilogue_pair<PB, true>(a, epi_s, acc[0], wave, l31, half, plane0, y0);
     else
-      conv_epilogue_pair<PB, false>(a, acc[0], wave, l31, half, plane0, y0);
+      conv_epilogue_pair<PB, false>(a, epi_s, acc[0], wave, l31, half, plane0, y0);
   } else if (TPAIR) {
     if constexpr (CB == 2) {
       if (a.w2) {                                      // fused 1x1 output conv: its weights [32][32] through LDS
@@ -781,25 +793,25 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
           reinterpret_cast<float4*>(w2s)[i] = reinterpret_cast<const float4*>(a.w2)[i];
         __syncthreads();
         if (a.flags & FVP_EPI_RES)
-          conv_epilogue_tpair<CB, PB, true, true>(a, acc, wave, l31, half, plane0, y0, tapT, w2s);
+          conv_epilogue_tpair<CB, PB, true, true>(a, epi_s, acc, wave, l31, half, plane0, y0, tapT, w2s, epi_s + 3 * a.coutp);
         else
-          conv_epilogue_tpair<CB, PB, false, true>(a, acc, wave, l31, half, plane0, y0, tapT, w2s);
+          conv_epilogue_tpair<CB, PB, false, true>(a, epi_s, acc, wave, l31, half, plane0, y0, tapT, w2s, epi_s + 3 * a.coutp);
         return;
       }
     }
     if (a.flags & FVP_EPI_RES)
-      conv_epilogue_tpair<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, tapT);
+      conv_epilogue_tpair<CB, PB, true>(a, epi_s, acc, wave, l31, half, plane0, y0, tapT);
     else
-      conv_epilogue_tpair<CB, PB, false>(a, acc, wave, l31, half, plane0, y0, tapT);
+      conv_epilogue_tpair<CB, PB, false>(a, epi_s, acc, wave, l31, half, plane0, y0, tapT);
   } else if (a.ntapT > 1 || (a.ablate & 16)) {          // transposed conv: strided outputs, scalar stores
     if (a.flags & FVP_EPI_RES)
-      conv_epilogue<CB, PB, true>(a, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
+      conv_epilogue<CB, PB, true>(a, epi_s, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
     else
-      conv_epilogue<CB, PB, false>(a, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
+      conv_epilogue<CB, PB, false>(a, epi_s, acc, wave, l31, half, plane0, y0, 0, co0, tapT);
   } else if (a.flags & FVP_EPI_RES) {
-    conv_epilogue_wide<CB, PB, true>(a, acc, smem + 4, wave, lane, plane0, y0, co0);
+    conv_epilogue_wide<CB, PB, true>(a, epi_s, acc, smem + 4, wave, lane, plane0, y0, co0);
   } else {
-    conv_epilogue_wide<CB, PB, false>(a, acc, smem + 4, wave, lane, plane0, y0, co0);
+    conv_epilogue_wide<CB, PB, false>(a, epi_s, acc, smem + 4, wave, lane, plane0, y0, co0);
   }
 }
 
@@ -1125,7 +1137,8 @@ static int plan_and_launch_tpair(const FvpConvOp& op, ConvArgs a, const float* p
   a.vec = a.dma = 1;
   a.zeros = params;
   const size_t per_ch = (size_t(a.TN) * a.TH * (a.TW + 4) + size_t(32) * CB) * sizeof(float);
-  int CC = int((kLdsBudget - 64) / (per_ch * 2)) & ~1;
+  const size_t epi_bytes = (size_t(3) * op.coutp + 96) * sizeof(float);     // BN vectors (+ the fused 1x1 conv's) in LDS
+  int CC = int((kLdsBudget - 64 - epi_bytes) / (per_ch * 2)) & ~1;
   if (CC > op.cinp) CC = op.cinp;
   if (CC < 2) return FVP_ELIMIT;
   while (CC > 2 && size_t(CC) * a.TN * a.TH * (a.TW / 4 + 1) + 1 > 2048) CC -= 2;
@@ -1135,7 +1148,9 @@ static int plan_and_launch_tpair(const FvpConvOp& op, ConvArgs a, const float* p
   a.m_qpr = make_magic(a.TW / 4 + 1);
   a.m_rpc = make_magic(a.TN * a.TH);
   a.m_thp = make_magic(a.TH);
-  const size_t lds = std::max<size_t>(16 + 2 * (per_ch * CC + 16), 16 + 16384);
+  const size_t lds0 = (std::max<size_t>(16 + 2 * (per_ch * CC + 16), 16 + 16384) + 15) & ~size_t(15);
+  a.epi_off = int(lds0 / sizeof(float));
+  const size_t lds = lds0 + epi_bytes;
   dim3 grid(a.tiles_y * ceil_div(planes, a.TN), 1, 2);
   ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * 4.0 * hw * planes, 1, prof_level() >= 2);
   if (CB == 2)
@@ -1251,7 +1266,8 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   const int kt = pair ? kw + 1 : kw;               // taps per kernel row in the packed layout
   const size_t per_ch = (size_t(a.TN) * (a.TH + kh - 1) * twp + size_t(kh) * kt * 32 * CB) * sizeof(float);
   // the pipelined kernel keeps two chunks in LDS
-  int CC = int((kLdsBudget - 64) / (per_ch * (a.dma ? 2 : 1))) & ~1;
+  const size_t epi_bytes = a.dma ? (size_t(3) * op.coutp + 96) * sizeof(float) : 0;   // BN vectors in LDS (k_conv_dma)
+  int CC = int((kLdsBudget - 64 - epi_bytes) / (per_ch * (a.dma ? 2 : 1))) & ~1;
   if (CC > op.cinp) CC = op.cinp;
   if (CC < 2) return FVP_ELIMIT;
   if (a.dma)                                          // k_conv_dma keeps <= 8 staging items per lane
@@ -1268,15 +1284,20 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   a.m_rpc = make_magic(a.TN * (a.TH + kh - 1));
   a.m_thp = make_magic(a.TH + kh - 1);
   const size_t xs_floats = (size_t(CC) * a.TN * (a.TH + kh - 1) * twp + 3) & ~size_t(3);
-  const size_t lds = a.dma ? std::max<size_t>(16 + 2 * (per_ch * CC + 16), 16 + 16384)
-                           : (xs_floats + size_t(CC) * kh * kt * 32 * CB) * sizeof(float);
+  size_t lds = a.dma ? std::max<size_t>(16 + 2 * (per_ch * CC + 16), 16 + 16384)
+                     : (xs_floats + size_t(CC) * kh * kt * 32 * CB) * sizeof(float);
+  if (ksplit) lds = std::max<size_t>(lds, 16 + size_t(3) * PB * 16 * 64 * sizeof(float));   // partial tiles of waves 1..3
+  if (a.dma) {
+    lds = (lds + 15) & ~size_t(15);
+    a.epi_off = int(lds / sizeof(float));
+    lds += epi_bytes;
+  }
   dim3 grid(a.tiles_x * a.tiles_y * pgroups, CBfull / CB, a.ntapT);
   // algorithmic FLOPs (2*MAC on the true channel counts)
   const double taps = tr ? double(a.ntapT) : double(op.kh * op.kw);
   ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * taps * op.h * op.w * planes, 1, prof_level() >= 2);
   if (ksplit) {
-    const size_t lds_ks = std::max<size_t>(lds, 16 + size_t(3) * PB * 16 * 64 * sizeof(float));
-    hipLaunchKernelGGL((k_conv_dma<3, 3, 1, 1, false, false, true>), grid, dim3(256), lds_ks, s, a);
+    hipLaunchKernelGGL((k_conv_dma<3, 3, 1, 1, false, false, true>), grid, dim3(256), lds, s, a);
     return launch_status();
   }
   if (pair) {
