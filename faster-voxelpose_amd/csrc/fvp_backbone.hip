@@ -28,14 +28,16 @@
 #include "fvp_common.h"
 
 // ring slots of the LDS-DMA kernel's 128-cout configurations (chunks in flight = slots - 1).  Measured on the MI355X
-// (40 images, round 3, with the plain chunk barrier): 32-wide chunks 2 -> 3 slots (72 KB, still inside the epilogue's
-// 73.7 KB: two workgroups per CU) K-heavy 1x1 layers -5 %, pass 9.04 -> 8.93 ms; four slots (96 KB: one workgroup per
-// CU) 9.35 ms; 64-wide chunks with three slots (144 KB) cost the big transposed conv 7 %: two.
+// (40 images, round 3, with the plain chunk barrier): 32-wide chunks with three slots (72 KB, inside the epilogue's 73.7 KB)
+// K-heavy 1x1 layers -5 %, backbone pass 9.04 -> 8.93 ms - but with two batches in flight the images -> joints leg of
+// bench.py then came out bimodal (361-440 instead of 690 frames/s in 3 of 7 fresh processes, the serial rate unchanged;
+// cause not established), so both configurations stay at two slots; four slots (96 KB: one workgroup per CU) 9.35 ms;
+// 64-wide chunks with three slots (144 KB) cost the big transposed conv 7 %.
 #ifndef FVP_BB_SLOTS_128_64
 #define FVP_BB_SLOTS_128_64 2
 #endif
 #ifndef FVP_BB_SLOTS_128_32
-#define FVP_BB_SLOTS_128_32 3
+#define FVP_BB_SLOTS_128_32 2
 #endif
 #ifndef FVP_BB_NBUF
 #define FVP_BB_NBUF 1
