@@ -52,6 +52,13 @@
 #ifndef FVP_WINO_EPI_FAST
 #define FVP_WINO_EPI_FAST 1
 #endif
+// 1: the K loop's LDS-DMA uses buffer addressing (no vector instruction per chunk), 0: per-lane global addresses
+#ifndef FVP_WINO_BUF_DMA
+#define FVP_WINO_BUF_DMA 1
+#endif
+#ifndef FVP_WINO_ZERO_C
+#define FVP_WINO_ZERO_C 1
+#endif
 #ifndef FVP_WINO_ASM_DMA
 #define FVP_WINO_ASM_DMA 1
 #endif
@@ -83,6 +90,7 @@ __device__ __forceinline__ void lds_dma16(const float* g, const float* lds, int 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Column pass of the input transform on register pairs E = (t0, t3), M = (t1, t2):
 //   v03 = (t0 - t2, t1 - t3)   v12 = (t1 + t2, t2 - t1)
@@ -159,12 +167,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   auto wchunk = [&](const float* slot, int k) { return RESW ? wres + k * WCH : slot + xs_sz; };
 
   f32x4 acc[2][16];
+#if !FVP_WINO_ZERO_C
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[cb][p][r] = 0.0f;
+#endif
 
   const int HW = a.H * W;
   const int qpr = (W >> 2) + 1;
@@ -174,6 +184,73 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   const int nps = a.wino_ni + NW;                    // DMA instructions per wave per chunk (uniform)
 
   constexpr int kMaxIn = 4;                          // host guarantees wino_ni <= kMaxIn
+  const size_t in_step = size_t(CC) * HW, w_step = size_t(CC) * a.coutp * 16;
+  // this lane's weight item j: channel ci0 + j * DCI of the chunk, quad qd0 of the cout block's row
+  constexpr int DCI = NWV * 64 / (CBW * 4);
+  const int wit = wave * 64 + lane;
+  const size_t woff0 = size_t(wit / (CBW * 4)) * a.coutp * 16 + 4 * (wit % (CBW * 4));
+  const size_t wdj = size_t(DCI) * a.coutp * 16;
+  int su = u, sk = 0;                                // DMA cursor (unit su, chunk sk)
+#if FVP_WINO_BUF_DMA && !defined(HIPEMU)
+  // ---- DMA through buffer addressing (round 3).  On this part the fp32 MFMA runs on the vector ALUs: a VALU
+  // instruction of EITHER wave of a SIMD takes matrix time away (tools/micro/coexec.hip: MFMA bursts of one wave + a
+  // VALU stream of the other = 0.98 + 0.7 x 0.50 ms, not max), and the global-address form spent ~8 VALU instructions per
+  // DMA item and chunk (64-bit select between the image and the zero page, pointer add, readfirstlane for M0).  As a
+  // buffer load the item is: descriptor (SGPRs: the unit's base, set when the cursor enters a unit) + per-lane 32-bit byte
+  // offset (VGPR, per unit) + chunk offset (SGPR) -> NO vector instruction per chunk; lanes outside the image carry an
+  // offset that fails the range check and the hardware writes zeros to LDS (tools/micro/buflds.hip), so the zero page
+  // and the select are gone too.
+  constexpr unsigned kOOB = 0x80000000u;             // + any chunk offset (< 2^31) still fails the range check
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = unsigned(size_t((const __attribute__((address_space(3))) float*)smem));
+  unsigned voff[kMaxIn];                             // this lane's input items: byte offset from (unit base - one row), or kOOB
+  const unsigned woffb = unsigned(woff0) * 4u;       // this lane's weight item 0 (bytes from the unit's cout block, chunk 0)
+  i32x4 rs_in = {0, 0, 0x7ffffff0, 0x00020000}, rs_w = {0, 0, 0x7ffffff0, 0x00020000};   // raw buffers, stride 0
+  auto set_base = [](i32x4& rs, const float* p) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    rs[0] = __builtin_amdgcn_readfirstlane(int(unsigned(b)));
+    rs[1] = __builtin_amdgcn_readfirstlane(int(unsigned(b >> 32) & 0xffffu));
+  };
+  auto enter_unit = [&](int su_) {
+    const int st = fdiv(su_, a.m_ys), sy = su_ - st * a.ysplit;
+    const int spg = fdiv(st, a.m_ty), sty = st - spg * a.tiles_y;
+    const int splane0 = spg * a.TN, sy0 = sty * a.TH;
+    // row 0 of a slot is image row sy0 - 1: the descriptor starts one row above the band so that offsets are >= 0
+    set_base(rs_in, a.src + size_t(splane0) * a.cin * HW + sy0 * W - W);
+    set_base(rs_w, a.wts + size_t(sy) * (CBW * 16));
+#pragma unroll
+    for (int j = 0; j < kMaxIn; ++j) {
+      voff[j] = kOOB;
+      const int it = (wave + NWV * j) * 64 + lane;
+      if (j < a.wino_ni && it < nin) {
+        const int row = fdiv(it, a.m_qpr), qd = it - row * qpr;
+        const int ci = fdiv(row, a.m_rpc);
+        const int rem = row - ci * rows_per_ch;
+        const int n = fdiv(rem, a.m_thp), ry = rem - n * THp;
+        if (qd > 0 && ci < CC && unsigned(sy0 + ry - 1) < unsigned(a.H) && splane0 + n < a.planes)
+          voff[j] = unsigned((n * a.cin + ci) * HW + ry * W + 4 * (qd - 1)) * 4u;
+      }
+    }
+  };
+  auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(la), "v"(vo), "s"(rs), "s"(so)
+                 : "memory", "m0");
+  };
+  // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
+  auto stage = [&](int k, int boff) {
+    const unsigned so_in = unsigned(k) * unsigned(in_step) * 4u;
+    const unsigned la0 = lds0 + 4u * unsigned(4 + boff + wave_s * 256);
+#pragma unroll
+    for (int j = 0; j < kMaxIn; ++j)
+      if (j < a.wino_ni) buf_dma16(voff[j], rs_in, so_in, la0 + unsigned(NWV * j) * 1024u);
+    const unsigned so_w = unsigned(k) * unsigned(w_step) * 4u;
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+      buf_dma16(woffb, rs_w, so_w + unsigned(j) * unsigned(wdj) * 4u, la0 + unsigned(xs_sz + NWV * j * 256) * 4u);
+  };
+#else
   // unit-invariant part of this lane's input DMA items: offset relative to the unit's first
   // (plane, channel chunk, row band) and {row in slot, plane in group, channel in chunk}
   int rel_off[kMaxIn], meta[kMaxIn];
@@ -198,7 +275,6 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // per chunk a DMA item then costs a pointer add and a select (the address code used to be ~600
   // instructions per chunk and wave, issued between the MFMA bursts of the other wave of the SIMD).
   // The host guarantees cin % CC == 0 (no partial channel chunks).
-  int su = u, sk = 0;
   const float* ubase = a.src;                        // uniform: the cursor unit's (plane group, row band), channel 0
   const float* gwbase = a.wts;                       // uniform: the cursor unit's cout block, channel 0
   unsigned okmask = 0;                               // per lane: bit j <=> item j reads the image, else the zero page
@@ -216,12 +292,6 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       okmask |= ok ? (1u << j) : 0u;
     }
   };
-  const size_t in_step = size_t(CC) * HW, w_step = size_t(CC) * a.coutp * 16;
-  // this lane's weight item j: channel ci0 + j * DCI of the chunk, quad qd0 of the cout block's row
-  constexpr int DCI = NWV * 64 / (CBW * 4);
-  const int wit = wave * 64 + lane;
-  const size_t woff0 = size_t(wit / (CBW * 4)) * a.coutp * 16 + 4 * (wit % (CBW * 4));
-  const size_t wdj = size_t(DCI) * a.coutp * 16;
   // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
   auto stage = [&](int k, int boff) {
     const float* bk = ubase + size_t(k) * in_step;
@@ -240,6 +310,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       lds_dma16(wk + j * wdj, smem, 4 + boff + xs_sz + g * 256, 0);
     }
   };
+#endif
   enter_unit(su);
   auto advance_cursor = [&]() {
     if (++sk == nchunks) {
@@ -279,14 +350,28 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     tM[2] = dM[2] - dM[1];  tE[2] = dE[2] - dE[1];
     tM[3] = dM[1] - dM[3];  tE[3] = dE[1] - dE[3];
   };
-  auto mfma16 = [&](int cb) {
+  // first = the unit's first step: the MFMAs take the constant 0 as C.  (Clearing the 128 accumulator registers between
+  // units cost 128 vector moves per wave and unit - and on this part a vector instruction of either wave of a SIMD is
+  // matrix time lost, see the DMA note above.)
+  auto mfma16 = [&](int cb, bool first) {
     if (FVP_WINO_DIAG && (a.ablate & 4)) return;                        // diagnostics: no MFMA
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (first) {
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi) {
-      acc[cb][4 * xi + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].x, v03[xi].x, acc[cb][4 * xi + 0], 0, 0, 0);
-      acc[cb][4 * xi + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].y, v12[xi].x, acc[cb][4 * xi + 1], 0, 0, 0);
-      acc[cb][4 * xi + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].z, v12[xi].y, acc[cb][4 * xi + 2], 0, 0, 0);
-      acc[cb][4 * xi + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].w, v03[xi].y, acc[cb][4 * xi + 3], 0, 0, 0);
+      for (int xi = 0; xi < 4; ++xi) {
+        acc[cb][4 * xi + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].x, v03[xi].x, z, 0, 0, 0);
+        acc[cb][4 * xi + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].y, v12[xi].x, z, 0, 0, 0);
+        acc[cb][4 * xi + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].z, v12[xi].y, z, 0, 0, 0);
+        acc[cb][4 * xi + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].w, v03[xi].y, z, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        acc[cb][4 * xi + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].x, v03[xi].x, acc[cb][4 * xi + 0], 0, 0, 0);
+        acc[cb][4 * xi + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].y, v12[xi].x, acc[cb][4 * xi + 1], 0, 0, 0);
+        acc[cb][4 * xi + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].z, v12[xi].y, acc[cb][4 * xi + 2], 0, 0, 0);
+        acc[cb][4 * xi + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb][xi].w, v03[xi].y, acc[cb][4 * xi + 3], 0, 0, 0);
+      }
     }
   };
 
@@ -330,7 +415,9 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   fetch_a(0, wchunk(smem + 4, 0), 0);
   fetch_d(smem + 4, 0, WP);
   while (true) {
-  for (int k = 0; k < nchunks; ++k) {
+  // the chunk body exists twice: the unit's first chunk (its first step's MFMAs take C = 0) and every other one
+  auto chunk = [&](int k, auto firstc) {
+    constexpr bool kFirst = decltype(firstc)::value;
     const int nxt_off = cur_off + buf_sz >= 3 * buf_sz ? 0 : cur_off + buf_sz;
     const int nn_off = nxt_off + buf_sz >= 3 * buf_sz ? 0 : nxt_off + buf_sz;
 #if FVP_WINO_TIMING
@@ -387,7 +474,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       FVP_TS(tC);
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      mfma16(0);
+      mfma16(0, kFirst && s == 0);
       __builtin_amdgcn_sched_barrier(0);
       FVP_TS(tD);
       // ---- half-step 1: cout block 1; the last one of a chunk crosses into the next slot
@@ -425,12 +512,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       FVP_TS(tF);
-      mfma16(1);
+      mfma16(1, kFirst && s == 0);
       __builtin_amdgcn_sched_barrier(0);
       FVP_TS(tG);
     }
     cur_off = nxt_off;
-  }
+  };
+  if (FVP_WINO_ZERO_C) chunk(0, std::integral_constant<bool, true>{});
+  for (int k = FVP_WINO_ZERO_C ? 1 : 0; k < nchunks; ++k) chunk(k, std::integral_constant<bool, false>{});
 
   // ---- unit finished: output transform + epilogue, then the next unit of this workgroup
 #if FVP_WINO_TIMING
@@ -545,12 +634,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // the first chunk barrier of the next unit lets them stay in flight instead of waiting for their round trip
   st_pending = FVP_WINO_STORES_IN_FLIGHT ? 16 + (a.pool_dst ? 8 : 0) : 0;
   }
+#if !FVP_WINO_ZERO_C
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[cb][p][r] = 0.0f;
+#endif
 #if FVP_WINO_TIMING
   {
     __builtin_amdgcn_sched_barrier(0);
