@@ -45,7 +45,8 @@
 #ifndef FVP_WINO_STORES_IN_FLIGHT
 #define FVP_WINO_STORES_IN_FLIGHT 1
 #endif
-// K-loop ablation switches (FVP_CONV_ABLATE bits 4, 64, 128, 256, 512) only exist in a diagnostics build
+// Ablation switches other than 1 (no DMA) and 8 (no epilogue) - FVP_CONV_ABLATE bits 4, 16, 32, 64, 128, 256, 512, 1024 -
+// only exist in a diagnostics build
 #ifndef FVP_WINO_DIAG
 #define FVP_WINO_DIAG 0
 #endif
@@ -547,7 +548,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   FVP_OPAQUE(bs);
   const float* const epi_s = smem + 4 + 3 * bs + (RESW ? a.cinp * CBW * 16 : 0);
   // element offset of (cout co4 + r, this lane's tile); padded couts and masked tiles read a valid address and store nothing
-  const unsigned omask = (a.ablate & 1024) ? 0x3ffffu : ~0u;   // (bit 1024, diagnostics: epilogue traffic stays inside 1 MB)
+  const unsigned omask = (FVP_WINO_DIAG && (a.ablate & 1024)) ? 0x3ffffu : ~0u;   // (bit 1024, diagnostics: epilogue traffic stays inside 1 MB)
   auto out_off = [&](int co) { return ((cbase + (tile_ok && co < a.cout ? co : 0)) * unsigned(HW) + pix) & omask; };
   float2 r0[2][4], r1[2][4];
 #pragma unroll
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     for (int r = 0; r < 4; ++r) {
       const unsigned off = out_off(co4 + r);
       if (HAS_RES) {
-        if (a.ablate & 16) {                         // diagnostics: no residual loads
+        if (FVP_WINO_DIAG && (a.ablate & 16)) {       // diagnostics: no residual loads
           r0[cb][r] = r1[cb][r] = make_float2(0.f, 0.f);
         } else {
           r0[cb][r] = *reinterpret_cast<const float2*>(a.res + off);
@@ -595,7 +596,10 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // every P2PNet / CenterNet layer on this kernel is BN (+ residual) -> ReLU: that order gets its own copy of the loop (as
   // run-time flags the two selects per value were a quarter of the epilogue's instructions)
   auto finalize = [&](auto fast) {
+    // kFast: BN (+ residual) -> ReLU and every cout of the block exists (cout % 32 == 0): one predicate (the lane's tile)
+    // for all stores, no per-cout compare, no select in the addresses (masked lanes compute on plane 0 / pixel 0)
     constexpr bool kFast = decltype(fast)::value;
+    float v[2][4][2][2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int co4 = co0 + wc * 32 + cb * 16 + 4 * k4;
@@ -607,7 +611,6 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         const float b = bn[0][r], sc = bn[1][r], sh = bn[2][r];
         const float rr[2][2] = {{HAS_RES ? r0[cb][r].x : 0.f, HAS_RES ? r0[cb][r].y : 0.f},
                                 {HAS_RES ? r1[cb][r].x : 0.f, HAS_RES ? r1[cb][r].y : 0.f}};
-        float v[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -616,23 +619,48 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
             if (HAS_RES && (kFast || !res_after)) x += rr[i][e];
             if (kFast || relu) x = fmaxf(x, 0.0f);
             if (HAS_RES && !kFast && res_after) x += rr[i][e];
-            v[i][e] = x;
+            v[cb][r][i][e] = x;
           }
-        if (tile_ok && co4 + r < a.cout && (!(a.ablate & 32) || v[0][0] == 1.2345e-30f)) {   // (bit 32, diagnostics: no stores)
+        if (!kFast && tile_ok && co4 + r < a.cout &&
+            (!(FVP_WINO_DIAG && (a.ablate & 32)) || v[cb][r][0][0] == 1.2345e-30f)) {   // (bit 32, diagnostics: no stores)
           const unsigned off = out_off(co4 + r);
-          *reinterpret_cast<float2*>(a.dst + off) = make_float2(v[0][0], v[0][1]);
-          *reinterpret_cast<float2*>(a.dst + off + W) = make_float2(v[1][0], v[1][1]);
-          if (a.pool_dst)                              // fused max_pool(2,2): this lane's tile is one pooled pixel
-            a.pool_dst[(cbase + co4 + r) * unsigned(HW >> 2) + ppix] = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
+          *reinterpret_cast<float2*>(a.dst + off) = make_float2(v[cb][r][0][0], v[cb][r][0][1]);
+          *reinterpret_cast<float2*>(a.dst + off + W) = make_float2(v[cb][r][1][0], v[cb][r][1][1]);
+          if (a.pool_dst)                            // fused max_pool(2,2): this lane's tile is one pooled pixel
+            a.pool_dst[(cbase + co4 + r) * unsigned(HW >> 2) + ppix] =
+                fmaxf(fmaxf(v[cb][r][0][0], v[cb][r][0][1]), fmaxf(v[cb][r][1][0], v[cb][r][1][1]));
         }
       }
     }
+    if (kFast && tile_ok) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wc * 32 + cb * 16 + 4 * k4 + r;
+          const unsigned off = (cbase + unsigned(co)) * unsigned(HW) + pix;
+          *reinterpret_cast<float2*>(a.dst + off) = make_float2(v[cb][r][0][0], v[cb][r][0][1]);
+          *reinterpret_cast<float2*>(a.dst + off + W) = make_float2(v[cb][r][1][0], v[cb][r][1][1]);
+          if (a.pool_dst)
+            a.pool_dst[(cbase + unsigned(co)) * unsigned(HW >> 2) + ppix] =
+                fmaxf(fmaxf(v[cb][r][0][0], v[cb][r][0][1]), fmaxf(v[cb][r][1][0], v[cb][r][1][1]));
+        }
+    }
   };
-  if (FVP_WINO_EPI_FAST && relu && !res_after) finalize(std::integral_constant<bool, true>{});
+  const bool fast = FVP_WINO_EPI_FAST && relu && !res_after && (a.cout & 31) == 0 && !(FVP_WINO_DIAG && (a.ablate & 32));
+  if (fast) finalize(std::integral_constant<bool, true>{});
   else finalize(std::integral_constant<bool, false>{});
-  // the stores above sit in the (in-order) vmcnt queue BEHIND chunk 1 of the next unit, which was requested before them:
-  // the first chunk barrier of the next unit lets them stay in flight instead of waiting for their round trip
-  st_pending = FVP_WINO_STORES_IN_FLIGHT ? 16 + (a.pool_dst ? 8 : 0) : 0;
+  // The stores above sit in the (in-order) vmcnt queue BEHIND chunk 1 of the next unit, which was requested before them:
+  // the first chunk barrier of the next unit lets them stay in flight instead of waiting for their round trip.  Only
+  // when their number is KNOWN: in the fast form a wave issues all of them iff any of its lanes owns a tile (a store
+  // block with an empty exec mask may be branched over), and a wave's first lane owns its first tile - tiles, rows and
+  // planes grow with the lane.  Counting stores that were not issued would let the wait pass before chunk 1 has landed.
+#if defined(HIPEMU)
+  st_pending = 0;
+#else
+  st_pending = (FVP_WINO_STORES_IN_FLIGHT && fast && __builtin_amdgcn_readfirstlane(int(tile_ok)) != 0)
+                   ? 16 + (a.pool_dst ? 8 : 0) : 0;
+#endif
   }
 #if !FVP_WINO_ZERO_C
 #pragma unroll
