@@ -26,7 +26,9 @@ for s in "${srcs[@]}"; do
     # no fma contraction there (HIP's __fmul_rn/__fadd_rn are plain operators); the MFMA conv
     # file keeps the default.
     extra=(-ffp-contract=off)
-    [[ "$s" == "fvp_conv.hip" ]] && extra=()
+    # fvp_conv.hip: default contraction; its LDS-DMA inline asm writes M0 and says so in the clobber list, which hipcc
+    # accepts with a warning per instantiation ("reserved register": 346 of them) - silenced, the clobber stays
+    [[ "$s" == "fvp_conv.hip" ]] && extra=(-Wno-inline-asm)
     # (a failed compile must not leave the previous object behind to be linked)
     ( "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" -c "${here}/$s" -o "$o.tmp" && mv "$o.tmp" "$o" || { rm -f "$o" "$o.tmp"; exit 1; } ) &
     pids+=($!)
