@@ -42,7 +42,14 @@ constexpr int kStageS = 8;   // same for the 4-byte generic path
 // 0 <= x < 2^32/d; d == 1 is flagged by magic == 0).  Runtime integer division costs ~40 VALU
 // instructions on gfx950; the index arithmetic of a workgroup used to contain ~90 of them.
 __device__ __forceinline__ int fdiv(int x, unsigned magic) { return magic ? int(__umulhi(unsigned(x), magic)) : x; }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 static unsigned make_magic(int d) { return d <= 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; }
+
+// 1: k_conv_dma's chunk DMA uses buffer addressing (no vector instruction per item and chunk), 0: per-lane global addresses
+#ifndef FVP_CONV_BUF_DMA
+#define FVP_CONV_BUF_DMA 1
+#endif
 
 struct ConvArgs {
   const float* src;
@@ -633,25 +640,104 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
   // The (row, quad) decomposition of this lane's staging items does not depend on the chunk:
   // do the integer divisions once, keep {source offset within the chunk, channel} per item.
   constexpr int kMaxIn = 8;                          // host guarantees nin <= kMaxIn * 256
-  int in_off[kMaxIn], in_ci[kMaxIn];
+#if FVP_CONV_BUF_DMA && !defined(HIPEMU)
+  // (the paired transposed conv keeps the global-address form: with the fused 1x1 head it sits at its 168-register cap and
+  // the buffer form spilled 179 dwords there)
+  constexpr bool kBuf = !TPAIR;
+#else
+  constexpr bool kBuf = false;
+#endif
+  constexpr unsigned kOOB = 0x80000000u;             // an offset that fails the buffer range check: the DMA writes zeros
+  unsigned vin[kMaxIn];                              // kBuf: byte offset of item j from the plane group's first element, or kOOB
+  unsigned ci_pack[kMaxIn / 4] = {};                 // kBuf: channel-in-chunk of item j, 8 bits each (ragged last chunk)
+  int in_off[kMaxIn], in_ci[kMaxIn];                 // !kBuf: float offset (-1: zero page) and channel-in-chunk
 #pragma unroll
   for (int j = 0; j < kMaxIn; ++j) {
     const int it = (wave + 4 * j) * 64 + lane;
-    in_off[j] = -1;
-    in_ci[j] = 0;
+    int off = -1, cij = 0;
     if (it < nin) {
       const int row = fdiv(it, a.m_qpr), q = it - row * qpr;
       const int ci = fdiv(row, a.m_rpc);
       const int rem = row - ci * rows_per_ch;
       const int n = fdiv(rem, a.m_thp), ry = rem - n * THp;
       const int plane = plane0 + n, y = y0 + ry - padH;
-      in_ci[j] = ci;
+      cij = ci;
       if (q > 0 && ci < a.CC && plane < a.planes && y >= 0 && y < a.H)
-        in_off[j] = (n * a.cin + ci) * HW + y * W + 4 * (q - 1);
+        off = (n * a.cin + ci) * HW + y * W + 4 * (q - 1);
+    }
+    if constexpr (kBuf) {
+      vin[j] = off >= 0 ? unsigned(off) * 4u : kOOB;
+      ci_pack[j >> 2] |= unsigned(cij & 255) << (8 * (j & 3));
+    } else {
+      in_off[j] = off;
+      in_ci[j] = cij;
     }
   }
   const float* src_tile = a.src + size_t(plane0) * a.cin * HW;
-  auto stage = [&](int k, int buf) {
+  // Chunk DMA through buffer addressing (as in k_conv_wino, round 3): the fp32 MFMA shares the vector ALUs, so the ~8
+  // vector instructions per item of the global-address form (64-bit select against the zero page, pointer add) were matrix
+  // time of every wave of the SIMD.  Descriptors (SGPRs): the workgroup's plane group / its packed weight block; per-lane
+  // 32-bit byte offsets, chunk-invariant: one per input item, ONE for all weight items (item j + 1 lies 256 quads = a whole
+  // number of rows further: a uniform offset); the chunk offset is scalar.  Lanes outside the image carry an offset that
+  // fails the range check: the hardware writes zeros (tools/micro/buflds.hip).  Only a ragged last chunk (cin or cinp not
+  // a multiple of CC) masks per item.
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#if !defined(HIPEMU)
+  const unsigned lds0 = unsigned(size_t((const __attribute__((address_space(3))) float*)smem));
+#else
+  const unsigned lds0 = 0;
+#endif
+  auto make_rsrc = [](const float* p) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane(int(unsigned(b)));
+    rs[1] = __builtin_amdgcn_readfirstlane(int(unsigned(b >> 32) & 0xffffu));
+    rs[2] = 0x7ffffff0;
+    rs[3] = 0x00020000;
+    return rs;
+  };
+  const i32x4 rs_in = make_rsrc(src_tile), rs_w = make_rsrc(wts);
+  constexpr int QPRW = CBW / 4;                       // 16-byte quads per packed weight row
+  constexpr int RPI = 256 / QPRW;                     // weight rows between item j and item j + 1 of a lane
+  const int wit0 = wave * 64 + lane;
+  const int wrow0 = wit0 / QPRW;
+  const unsigned vw0 = unsigned(wrow0 * a.wrow + 4 * (wit0 % QPRW)) * 4u;
+  auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) {
+#if !defined(HIPEMU)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(la), "v"(vo), "s"(rs), "s"(so)
+                 : "memory", "m0");
+#endif
+  };
+  auto stage_buf = [&](int k, int buf) {
+    const int c0 = k * a.CC;
+    const unsigned la_x = lds0 + 4u * unsigned(4 + buf * buf_sz + wave_s * 256);
+    const unsigned la_w = la_x + 4u * unsigned(xs_sz);
+    const unsigned so_in = unsigned(c0) * unsigned(HW) * 4u;
+    const bool ragged = c0 + a.CC > a.cin || c0 + a.CC > a.cinp;      // uniform: only ever the last chunk
+#pragma unroll
+    for (int j = 0; j < kMaxIn; ++j) {
+      const int g = wave + 4 * j;
+      if (g * 64 + lane < nin) {
+        unsigned vo = vin[j];
+        if (ragged && c0 + int((ci_pack[j >> 2] >> (8 * (j & 3))) & 255u) >= a.cin) vo = kOOB;
+        buf_dma16(vo, rs_in, so_in, la_x + unsigned(j) * 4096u);
+      }
+    }
+    const int avail_rows = (a.cinp - c0) * KK;
+    const unsigned so_w = unsigned(c0) * unsigned(KK) * unsigned(a.wrow) * 4u;
+    const unsigned step_w = unsigned(RPI) * unsigned(a.wrow) * 4u;
+    int jj = 0;
+    for (int g = wave; g * 64 < nwq; g += 4, ++jj) {
+      if (g * 64 + lane < nwq) {
+        unsigned vo = vw0;
+        if (ragged && wrow0 + jj * RPI >= avail_rows) vo = kOOB;
+        buf_dma16(vo, rs_w, so_w + unsigned(jj) * step_w, la_w + unsigned(jj) * 4096u);
+      }
+    }
+  };
+  auto stage_glb = [&](int k, int buf) {
     float* xs = smem + 4 + buf * buf_sz;
     float* ws = xs + xs_sz;
     const int c0 = k * a.CC;
@@ -678,6 +764,11 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
     }
   };
 
+  auto stage = [&](int k, int buf) {
+    if constexpr (kBuf) stage_buf(k, buf);
+    else stage_glb(k, buf);
+  };
+
   // bias | scale | shift of every cout (+ the fused 1x1 conv's three 32-vectors) staged behind everything else in LDS: the
   // epilogues read them with ds_read.  As global loads they queued behind the previous element's stores in the in-order
   // vmcnt counter, and behind a conditional store the compiler can only wait with vmcnt(0): every output element of a
@@ -689,6 +780,7 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
     if (TPAIR && a.w2 && t < 96) e[3 * a.coutp + t] = a.epi2[t];
   }
   if (!(a.ablate & 3)) stage(0, 0);
+  wait_vmcnt(0);                                     // (the DMA is inline asm: the barrier's fence does not know it)
   __syncthreads();
   for (int k = 0; k < nchunks; ++k) {
     const int buf = k & 1;
@@ -750,6 +842,7 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
         if (ci + CSTEP < a.CC) block(std::integral_constant<int, 1>{}, ci + CSTEP);
       }
     }
+    wait_vmcnt(0);                                   // chunk k + 1 has landed (this wave's items; the barrier: everybody's)
     __syncthreads();
   }
   if (a.ablate & 8) return;
