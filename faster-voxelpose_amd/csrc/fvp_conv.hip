@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
   // The (row, quad) decomposition of this lane's staging items does not depend on the chunk:
   // do the integer divisions once, keep {source offset within the chunk, channel} per item.
   constexpr int kMaxIn = 8;                          // host guarantees nin <= kMaxIn * 256
-#if FVP_CONV_BUF_DMA && !defined(HIPEMU)
+#if FVP_CONV_BUF_DMA
   // (the paired transposed conv keeps the global-address form: with the fused 1x1 head it sits at its 168-register cap and
   // the buffer form spilled 179 dwords there)
   constexpr bool kBuf = !TPAIR;
@@ -703,7 +703,9 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
   const int wrow0 = wit0 / QPRW;
   const unsigned vw0 = unsigned(wrow0 * a.wrow + 4 * (wit0 % QPRW)) * 4u;
   auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) {
-#if !defined(HIPEMU)
+#if defined(HIPEMU)
+    hipemu_buffer_load_lds16(smem, la, vo, rs[0], rs[1], rs[2], so);
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(la), "v"(vo), "s"(rs), "s"(so)

@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   const size_t woff0 = size_t(wit / (CBW * 4)) * a.coutp * 16 + 4 * (wit % (CBW * 4));
   const size_t wdj = size_t(DCI) * a.coutp * 16;
   int su = u, sk = 0;                                // DMA cursor (unit su, chunk sk)
-#if FVP_WINO_BUF_DMA && !defined(HIPEMU)
+#if FVP_WINO_BUF_DMA
   // ---- DMA through buffer addressing (round 3).  On this part the fp32 MFMA runs on the vector ALUs: a VALU
   // instruction of EITHER wave of a SIMD takes matrix time away (tools/micro/coexec.hip: MFMA bursts of one wave + a
   // VALU stream of the other = 0.98 + 0.7 x 0.50 ms, not max), and the global-address form spent ~8 VALU instructions per
@@ -203,7 +203,11 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // and the select are gone too.
   constexpr unsigned kOOB = 0x80000000u;             // + any chunk offset (< 2^31) still fails the range check
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#if defined(HIPEMU)
+  const unsigned lds0 = 0;                           // (emulator: LDS addresses are byte offsets from smem)
+#else
   const unsigned lds0 = unsigned(size_t((const __attribute__((address_space(3))) float*)smem));
+#endif
   unsigned voff[kMaxIn];                             // this lane's input items: byte offset from (unit base - one row), or kOOB
   const unsigned woffb = unsigned(woff0) * 4u;       // this lane's weight item 0 (bytes from the unit's cout block, chunk 0)
   i32x4 rs_in = {0, 0, 0x7ffffff0, 0x00020000}, rs_w = {0, 0, 0x7ffffff0, 0x00020000};   // raw buffers, stride 0
@@ -234,10 +238,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     }
   };
   auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) {
+#if defined(HIPEMU)
+    hipemu_buffer_load_lds16(smem, la, vo, rs[0], rs[1], rs[2], so);
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(la), "v"(vo), "s"(rs), "s"(so)
                  : "memory", "m0");
+#endif
   };
   // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
   auto stage = [&](int k, int boff) {

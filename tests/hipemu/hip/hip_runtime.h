@@ -211,6 +211,22 @@ static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, 
 }
 #define __builtin_amdgcn_global_load_lds hipemu_glds
 
+// buffer_load_dwordx4 ... offen lds (raw buffer, stride 0): lane l copies 16 bytes from base + voffset + soffset to LDS
+// offset `la` + 16 l; every dword whose offset fails the range check (offset + 4 > num_records, the SGPR offset included)
+// is written as zero - what tools/micro/buflds.hip measured on gfx950.  `la` is a byte offset from the kernel's dynamic
+// LDS base (the kernels build it from lds0 = 0 in this build).
+static inline void hipemu_buffer_load_lds16(const void* lds_base, unsigned la, unsigned vo, int rs0, int rs1, int rs2, unsigned so) {
+  const unsigned long long base = (unsigned long long)(unsigned)rs0 | ((unsigned long long)((unsigned)rs1 & 0xffffu) << 32);
+  const unsigned long long nrec = (unsigned)rs2;
+  char* dst = (char*)lds_base + la + size_t(hipemu::cur->lane) * 16;
+  for (int d = 0; d < 4; ++d) {
+    const unsigned long long off = (unsigned long long)vo + so + 4ull * d;
+    float v = 0.0f;
+    if (off + 4 <= nrec) memcpy(&v, (const char*)base + off, 4);
+    memcpy(dst + 4 * d, &v, 4);
+  }
+}
+
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
