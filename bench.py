@@ -531,6 +531,9 @@ def main():
                                  if top == "k_conv_wino" else "algorithmic = executed"}
                 if top == "k_conv_wino":
                     roof["executed_mfma_frac"] = roof["frac"] * 4.0 / 9.0
+                    roof["note"] = ("achieved / frac count ALGORITHMIC FLOPs (direct-conv 2*MAC, SURVEY.md 8d) against the fp32 "
+                                    "MFMA peak, so frac can exceed 1: Winograd F(2x2,3x3) executes 16/36 of them; the share of "
+                                    "the matrix peak the kernel really runs at is executed_mfma_frac")
             # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
             # correction + WRITE_SIZE, mean per launch over the B = 8 launches of this very workload).  PMC counters
             # cannot be read from inside this process, so the figure is tagged with file, commit and date.
