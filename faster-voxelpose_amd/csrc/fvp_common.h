@@ -30,6 +30,15 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   }
 }
 
+// the same for n = 0..8 in a handful of scalar instructions (the 64-way form is a cascade of ~30 compares and branches,
+// paid by every wave at every chunk barrier); larger n fall through to the general form
+__device__ __forceinline__ void wait_vmcnt_small(int n) {
+  switch (n) {
+    FVP_VMCNT_CASE4(0) FVP_VMCNT_CASE4(4) FVP_VMCNT_CASE(8)
+    default: wait_vmcnt(n < 63 ? n : 63); break;
+  }
+}
+
 inline hipStream_t as_stream(fvp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Kernel-class timing used by bench.py's roofline leg (fvp_prof_*).

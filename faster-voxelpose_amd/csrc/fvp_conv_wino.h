@@ -496,9 +496,13 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
         // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
         if (dma) {
-          const int keep = (more ? nps : 0) + st_pending;
-          wait_vmcnt(keep < 63 ? keep : 63);
-          st_pending = 0;
+          if constexpr (kFirst || !FVP_WINO_ZERO_C) {  // a unit's first chunk: the previous epilogue's stores may count in
+            const int keep = (more ? nps : 0) + st_pending;
+            wait_vmcnt(keep < 63 ? keep : 63);
+            st_pending = 0;
+          } else {
+            wait_vmcnt_small(more ? nps : 0);          // nps <= 8: a handful of scalar instructions instead of ~30
+          }
         }
 #if FVP_WINO_TIMING
         __builtin_amdgcn_sched_barrier(0);
