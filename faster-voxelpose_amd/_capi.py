@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfvp_hip.so"
-ABI_VERSION = 4            # include/fvp.h FVP_ABI_VERSION
+ABI_VERSION = 5            # include/fvp.h FVP_ABI_VERSION
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 FVP_CAM_FLOATS = 24
@@ -55,6 +55,7 @@ SIGNATURES = {
     "fvp_heatmaps_to_cl": [_P, _P, _I, _G, _P],
     "fvp_sample_grid": [_P, _P, _P, _I, _I, _I, _P, _G, _P, _P],
     "fvp_project_whole": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _G, _P, _P, _P],
+    "fvp_project_columns": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _G, _P, _I, _P, _P],
     "fvp_zmax": [_P, _P, C.c_long, _I, _P],
     "fvp_person_boxes": [_P, _I, _P, _P, _P, _P, _P],
     "fvp_project_individual": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _G, _P, _P],

@@ -300,6 +300,47 @@ __device__ __forceinline__ void sample4(const float* __restrict__ cl, int JP, in
 // 64-byte run per tap (16 cache lines per wave instruction instead of 64 -- the gather is bound by
 // the texture-addresser line rate) and lane q computes the projection of view q for the quad
 // (DPP broadcast).  Same per-channel arithmetic as k_project_whole (bit-equal cubes).
+// the per-voxel body of the quad-lane form: mean over views of the bilinear samples of channels [16n + 4q, +4),
+// clamped to [0,1] (shared by the whole-space kernel and the proposal-column kernel, so both give the same bits)
+template <int NVL>
+__device__ __forceinline__ void whole_point_quad(const float* __restrict__ frame, const Cam* __restrict__ cm,
+                                                 const FvpGeom& g, int q, bool active, float wx, float wy, float wz,
+                                                 float (&out)[NVL][4]) {
+  const int JP = g.JP;
+  const size_t view_stride = size_t(g.H) * g.W * JP;
+  float acc[NVL][4];
+#pragma unroll
+  for (int n = 0; n < NVL; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[n][i] = 0.0f;
+  TapD mine;
+  mine.inside = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { mine.off[k] = 0; mine.w[k] = 0.0f; }
+  if (active && q < g.V) mine = make_taps(cm[q], g, wx, wy, wz);
+  auto add_view = [&](const TapD& tv, int v) {
+#pragma unroll
+    for (int n = 0; n < NVL; ++n) {
+      const int ch0 = 16 * n + 4 * q;
+      if (ch0 < JP) {
+        if (tv.inside) sample4(frame + v * view_stride, JP, ch0, tv, v == 0, acc[n]);
+        else if (v == 0) { acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f; }
+      }
+    }
+  };
+  { const TapD tv = quad_bcast<0>(mine); if (active) add_view(tv, 0); }
+  if (g.V > 1) { const TapD tv = quad_bcast<1>(mine); if (active) add_view(tv, 1); }
+  if (g.V > 2) { const TapD tv = quad_bcast<2>(mine); if (active) add_view(tv, 2); }
+  if (g.V > 3) { const TapD tv = quad_bcast<3>(mine); if (active) add_view(tv, 3); }
+  for (int v = 4; v < g.V; ++v)
+    if (active) add_view(make_taps(cm[v], g, wx, wy, wz), v);
+  const float nv = float(g.V);
+#pragma unroll
+  for (int n = 0; n < NVL; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[n][i] = clampf(__fdiv_rn(acc[n][i], nv), 0.0f, 1.0f);
+}
+
 template <int NVL>
 __global__ void __launch_bounds__(1024)
 k_project_whole_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cams,
@@ -336,33 +377,8 @@ k_project_whole_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cam
     wy = ay[y];
     wz = az[z];
   }
-  float acc[NVL][4];
-#pragma unroll
-  for (int n = 0; n < NVL; ++n)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[n][i] = 0.0f;
-  TapD mine;
-  mine.inside = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { mine.off[k] = 0; mine.w[k] = 0.0f; }
-  if (active && q < g.V) mine = make_taps(cm[q], g, wx, wy, wz);
-  auto add_view = [&](const TapD& tv, int v) {
-#pragma unroll
-    for (int n = 0; n < NVL; ++n) {
-      const int ch0 = 16 * n + 4 * q;
-      if (ch0 < JP) {
-        if (tv.inside) sample4(frame + v * view_stride, JP, ch0, tv, v == 0, acc[n]);
-        else if (v == 0) { acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.0f; }
-      }
-    }
-  };
-  { const TapD tv = quad_bcast<0>(mine); if (active) add_view(tv, 0); }
-  if (g.V > 1) { const TapD tv = quad_bcast<1>(mine); if (active) add_view(tv, 1); }
-  if (g.V > 2) { const TapD tv = quad_bcast<2>(mine); if (active) add_view(tv, 2); }
-  if (g.V > 3) { const TapD tv = quad_bcast<3>(mine); if (active) add_view(tv, 3); }
-  for (int v = 4; v < g.V; ++v)
-    if (active) add_view(make_taps(cm[v], g, wx, wy, wz), v);
-  const float nv = float(g.V);
+  float val[NVL][4];
+  whole_point_quad<NVL>(frame, cm, g, q, active, wx, wy, wz, val);
   const size_t vox = size_t(col) * Z + z;
   const size_t nvox = size_t(ncol) * Z;
 #pragma unroll
@@ -370,7 +386,7 @@ k_project_whole_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cam
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = 16 * n + 4 * q + i;
-      const float v = clampf(__fdiv_rn(acc[n][i], nv), 0.0f, 1.0f);
+      const float v = val[n][i];
       if (zmax) sm[c][vl] = active ? v : 0.0f;
       if (cubes && active && c < J) cubes[(size_t(b) * J + c) * nvox + vox] = v;
     }
@@ -386,6 +402,41 @@ k_project_whole_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cam
       }
     }
   }
+}
+
+// Proposal z-columns only (human_detection_net.py:92-93 gathers N columns of the cubes per frame and nothing else
+// of them is used by the fused forward): feat1d[b*N + k][c][z] = cubes[b][c][flat[b][k]][z], computed by the very
+// device function of k_project_whole_q (same bits as the materialised cubes), 61 MB of cube writes per 8 frames never
+// happen.  Workgroup = one proposal column: Z voxels x 4 lanes.
+template <int NVL>
+__global__ void __launch_bounds__(1024)
+k_project_columns_q(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
+                    const float* __restrict__ ax, const float* __restrict__ ay, const float* __restrict__ az, int Y,
+                    int Z, int ncol, int N, FvpGeom g, const long long* __restrict__ flat, float* __restrict__ feat1d) {
+  const int pi = blockIdx.x, b = pi / N;
+  const int t = threadIdx.x, q = t & 3, z = t >> 2;
+  const long long col = flat[pi];
+  const bool active = z < Z && col >= 0 && col < ncol;
+  const int J = g.J;
+  const size_t view_stride = size_t(g.H) * g.W * g.JP;
+  const float* frame = heat_cl + size_t(b) * g.V * view_stride;
+  const Cam* cm = cams + size_t(frame_set[b]) * g.V;
+  float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+  if (active) {
+    const int x = int(col) / Y, y = int(col) - x * Y;
+    wx = ax[x];
+    wy = ay[y];
+    wz = az[z];
+  }
+  float val[NVL][4];
+  whole_point_quad<NVL>(frame, cm, g, q, active, wx, wy, wz, val);
+#pragma unroll
+  for (int n = 0; n < NVL; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 16 * n + 4 * q + i;
+      if (z < Z && c < J) feat1d[(size_t(pi) * J + c) * Z + z] = active ? val[n][i] : 0.0f;
+    }
 }
 
 template <int NVL>   // channel quads per lane: ceil(JP/16)
@@ -654,6 +705,26 @@ extern "C" int fvp_project_whole(const float* heat_cl, const float* cams, const 
                      reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, X, Y, Z, *g, cubes, zmax);
   FVP_NV_SWITCH(g->JP / 4, CALL)
 #undef CALL
+  return launch_status();
+}
+
+extern "C" int fvp_project_columns(const float* heat_cl, const float* cams, const int32_t* frame_set, const float* ax,
+                                   const float* ay, const float* az, int X, int Y, int Z, int B, const FvpGeom* g,
+                                   const int64_t* flat, int N, float* feat1d, fvp_stream_t s) {
+  FVP_REQUIRE(heat_cl && cams && frame_set && ax && ay && az && flat && feat1d && X > 0 && Y > 0 && Z > 0 && N > 0);
+  if (int e = check_geom(g)) return e;
+  FVP_LIMIT(Z <= 256 && g->JP <= 32);
+  if (B == 0) return 0;
+  ProfScope ps(FVP_K_PROJECT_WHOLE, as_stream(s));
+  const int threads = ceil_div(4 * Z, 64) * 64;
+  if (g->JP <= 16)
+    hipLaunchKernelGGL(k_project_columns_q<1>, dim3(B * N), dim3(threads), 0, as_stream(s), heat_cl,
+                       reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, Y, Z, X * Y, N, *g,
+                       reinterpret_cast<const long long*>(flat), feat1d);
+  else
+    hipLaunchKernelGGL(k_project_columns_q<2>, dim3(B * N), dim3(threads), 0, as_stream(s), heat_cl,
+                       reinterpret_cast<const Cam*>(cams), frame_set, ax, ay, az, Y, Z, X * Y, N, *g,
+                       reinterpret_cast<const long long*>(flat), feat1d);
   return launch_status();
 }
 

@@ -119,7 +119,7 @@ k_gather(const float* __restrict__ bbox_map, const float* __restrict__ cubes, co
     const int b = int(r / N);
     match_bbox[i] = bbox_map[(size_t(b) * 2 + c) * XY + flat[r]];
   }
-  if (i < long(B) * N * J * Z) {                // feat1d[b*N+k][j][z] = cubes[b][j][flat][z]
+  if (cubes && i < long(B) * N * J * Z) {       // feat1d[b*N+k][j][z] = cubes[b][j][flat][z]
     const int z = int(i % Z);
     long r = i / Z;
     const int j = int(r % J);
@@ -182,9 +182,9 @@ extern "C" int fvp_nms_topk(const float* hm2d, int B, int X, int Y, int N, float
 extern "C" int fvp_gather_proposals(const float* bbox_map, const float* cubes, const int64_t* flat, int B, int J,
                                     int X, int Y, int Z, int N, float* bbox_flat, float* match_bbox, float* feat1d,
                                     fvp_stream_t s) {
-  FVP_REQUIRE(bbox_map && cubes && flat && match_bbox && feat1d && B >= 0);
+  FVP_REQUIRE(bbox_map && flat && match_bbox && B >= 0 && (cubes != nullptr) == (feat1d != nullptr));
   if (B == 0) return 0;
-  long total = long(B) * N * J * Z;
+  long total = cubes ? long(B) * N * J * Z : 0;
   if (bbox_flat && long(B) * X * Y * 2 > total) total = long(B) * X * Y * 2;
   if (long(B) * N * 2 > total) total = long(B) * N * 2;
   ProfScope ps(FVP_K_OTHER, as_stream(s));

@@ -104,6 +104,10 @@ class HotPath:
         self._person_frame = {}
         self._scratch = {}
         self.fused_c2c = True        # C2CNet as one kernel per batch (False: generic conv interpreter)
+        # HumanDetectionNet only ever reads N z-columns per frame of the whole-space cubes (human_detection_net.py:92-93):
+        # by default they are projected directly (fvp_project_columns, same bits) and the [B,J,X,Y,Z] cubes are never
+        # written.  True: materialise them (kept in self.last["cubes"]; the drop-in ProjectLayer always materialises).
+        self.keep_hdn_cubes = False
 
     # ---------------------------------------------------------------------------------------------
     def stream(self):
@@ -315,7 +319,8 @@ class HotPath:
         B = heatmaps.shape[0]
         N, J, X, Y, Z = self.N, self.J, self.X, self.Y, self.Z
         s = self.stream()
-        cubes, zmax = self.project_whole(heatmaps, meta, cameras, resize_transform, True, True)
+        keep = self.keep_hdn_cubes
+        cubes, zmax = self.project_whole(heatmaps, meta, cameras, resize_transform, keep, True)
         heads = self.run_stack("center_net", zmax, B)
         hm2d = heads["output_hm"].clone()
         bbox_map = heads["output_size"]
@@ -327,8 +332,17 @@ class HotPath:
         bbox_flat = torch.empty((B, X * Y, 2), device=dev)
         match_bbox = self.scratch("match_bbox", (B, N, 2))
         feat1d = self.scratch("feat1d", (B * N, J, 1, Z))
-        self._call("fvp_gather_proposals", _ptr(bbox_map), _ptr(cubes), _ptr(flat), B, J, X, Y, Z, N, _ptr(bbox_flat),
-                   _ptr(match_bbox), _ptr(feat1d), s)
+        if keep:
+            self._call("fvp_gather_proposals", _ptr(bbox_map), _ptr(cubes), _ptr(flat), B, J, X, Y, Z, N,
+                       _ptr(bbox_flat), _ptr(match_bbox), _ptr(feat1d), s)
+        else:
+            self._call("fvp_gather_proposals", _ptr(bbox_map), None, _ptr(flat), B, J, X, Y, Z, N, _ptr(bbox_flat),
+                       _ptr(match_bbox), None, s)
+            g = self.geom(resize_transform)
+            ax = self.whole_axes
+            self._call("fvp_project_columns", _ptr(self._heat_cl), _ptr(self._cams),
+                       _ptr(self.frame_sets(meta, cameras, heatmaps.shape[1])), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
+                       X, Y, Z, B, C.byref(g), _ptr(flat), N, _ptr(feat1d), s)
         if self.fused_c2c and Z <= 24:
             hm1d = self.run_stack_fused_1d("c2c_net", feat1d, B * N)["out"].view(B, N, Z).clone()
         else:
@@ -338,7 +352,7 @@ class HotPath:
         self._call("fvp_proposals", _ptr(hm1d), _ptr(conf2d), _ptr(idx2d), _ptr(match_bbox), _ptr(self.prop_sb),
                    self.min_score, B, N, Z, _ptr(topk_index), _ptr(centers), s)
         self.last = dict(cubes=cubes, zmax=zmax, conf2d=conf2d, idx2d=idx2d, flat=flat, topk_index=topk_index,
-                         bbox_map=bbox_map)
+                         bbox_map=bbox_map, feat1d=feat1d, hm2d=hm2d, hm1d=hm1d, bbox_flat=bbox_flat)
         return hm2d, hm1d, centers, bbox_flat
 
     def person_frame(self, B, N):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FVP_ABI_VERSION 4
+#define FVP_ABI_VERSION 5
 #define FVP_MAX_VIEWS 8
 #define FVP_CAM_FLOATS 24 /* R[9] T[3] fx fy cx cy k[3] p[2] + 3 pad */
 #define FVP_MAX_JOINTS 32
@@ -78,6 +78,16 @@ int fvp_sample_grid(const float* ax, const float* ay, const float* az, int nx, i
 int fvp_project_whole(const float* heat_cl, const float* cams, const int32_t* frame_set,
                       const float* ax, const float* ay, const float* az, int X, int Y, int Z, int B,
                       const FvpGeom* g, float* cubes, float* zmax, fvp_stream_t s);
+
+/* ---- a-8 without materialised cubes: the N proposal z-columns of every frame ------------------------
+ * feat1d[b*N + k][j][z] = cubes[b][j][flat[b][k]][z] WITHOUT the cubes: the same device function as
+ * fvp_project_whole evaluated on the N columns that human_detection_net.py:92-93 gathers (bit-equal to
+ * the gather from materialised cubes; tested).  flat [B][N] int64 from fvp_nms_topk; an index outside
+ * [0, X*Y) yields a zero column.  Used by the fused forward (HumanDetectionNet inside
+ * FasterVoxelPoseNet.forward), where nothing else of the 4*J*X*Y*Z bytes per frame is ever read. */
+int fvp_project_columns(const float* heat_cl, const float* cams, const int32_t* frame_set, const float* ax,
+                        const float* ay, const float* az, int X, int Y, int Z, int B, const FvpGeom* g,
+                        const int64_t* flat, int N, float* feat1d, fvp_stream_t s);
 
 /* z-max of already materialised cubes [n][Z] -> [n] (n = B*J*X*Y): the first statement of
  * CenterNet.forward (cnns_2d.py:174) when it is called on its own. */
@@ -192,7 +202,8 @@ int fvp_nms_topk(const float* hm2d, int B, int X, int Y, int N, float* vals, int
 
 /* ---- a-8: gathers at the top-k cells ------------------------------------------------------------
  * bbox_map [B][2][X][Y] -> bbox_flat [B][X*Y][2] (the 4th output of HumanDetectionNet.forward,
- * may be NULL) and match_bbox [B][N][2]; cubes [B][J][X][Y][Z] -> feat1d [B*N][J][Z].
+ * may be NULL) and match_bbox [B][N][2]; cubes [B][J][X][Y][Z] -> feat1d [B*N][J][Z]
+ * (cubes and feat1d may both be NULL: the columns then come from fvp_project_columns).
  * Replaces human_detection_net.py:88-93. */
 int fvp_gather_proposals(const float* bbox_map, const float* cubes, const int64_t* flat, int B, int J, int X,
                          int Y, int Z, int N, float* bbox_flat, float* match_bbox, float* feat1d,

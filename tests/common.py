@@ -46,13 +46,41 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
     """Exact checks on integer / index work, tolerance checks on floating point."""
     v = g["valid"]
     last = engine.last
-    # --- HDN: cubes are bit-exact by construction (same fp32 op order as the reference's CPU path)
+    # --- HDN: cubes are bit-exact by construction (same fp32 op order as the reference's CPU path).  The forward
+    # materialises them only when engine.keep_hdn_cubes is set (the callers of this function run both ways).
     sx, sy = g["cubes_sub_stride"]
-    cubes = last["cubes"].detach().cpu()
-    assert np.array_equal(cubes[:, :, ::sx, ::sy, :].numpy(), g["cubes_sub"]), "HDN cubes differ"
-    np.testing.assert_allclose(cubes.double().sum(dim=(1, 2, 3, 4)).numpy(), g["cubes_sum"], rtol=1e-12)
-    np.testing.assert_allclose((cubes.double() ** 2).sum(dim=(1, 2, 3, 4)).numpy(), g["cubes_sq"], rtol=1e-12)
-    assert torch.equal(last["zmax"].cpu(), cubes.max(dim=4)[0]), "fused z-max != max over the cubes"
+    if last["cubes"] is not None:
+        cubes = last["cubes"].detach().cpu()
+        assert np.array_equal(cubes[:, :, ::sx, ::sy, :].numpy(), g["cubes_sub"]), "HDN cubes differ"
+        np.testing.assert_allclose(cubes.double().sum(dim=(1, 2, 3, 4)).numpy(), g["cubes_sum"], rtol=1e-12)
+        np.testing.assert_allclose((cubes.double() ** 2).sum(dim=(1, 2, 3, 4)).numpy(), g["cubes_sq"], rtol=1e-12)
+        assert torch.equal(last["zmax"].cpu(), cubes.max(dim=4)[0]), "fused z-max != max over the cubes"
+        # the proposal columns (projected directly or gathered) are columns of these cubes
+        Bc, Jc = cubes.shape[:2]
+        cols = cubes.flatten(2, 3).permute(0, 2, 1, 3)                              # [B, XY, J, Z]
+        fl = last["flat"].cpu()
+        want = torch.stack([cols[b][fl[b]] for b in range(Bc)])                    # [B, N, J, Z]
+        assert torch.equal(last["feat1d"].cpu().view(want.shape), want), "proposal z-columns != columns of the cubes"
+    # --- HDN's public outputs (human_detection_net.py:76-104: hm2d, hm1d, proposal_centers, bbox_preds) against the
+    # reference's: conv outputs in another summation order (same bar as the conv-stack tests), indices exact
+    hm2d = last["hm2d"].detach().cpu().numpy()
+    assert hm2d.shape[1] == 1
+    np.testing.assert_allclose(hm2d[:, 0], g["hm2d"], rtol=1e-4, atol=2e-5, err_msg="hm2d (CenterNet heatmap head)")
+    np.testing.assert_allclose(last["hm1d"].detach().cpu().numpy(), g["hm1d"], rtol=1e-4, atol=2e-5,
+                               err_msg="hm1d (C2CNet output)")
+    Bh, _, Xh, Yh = hm2d.shape
+    bbox = last["bbox_flat"].detach().cpu().numpy()                                   # [B, X*Y, 2] (:88)
+    assert bbox.shape == (Bh, Xh * Yh, 2)
+    bmap = bbox.reshape(Bh, Xh, Yh, 2).transpose(0, 3, 1, 2)                          # back to [B,2,X,Y]
+    np.testing.assert_allclose(bmap[:, :, ::sx, ::sy], g["bbox_map_sub"], rtol=1e-4, atol=2e-5,
+                               err_msg="bbox_preds (CenterNet size head)")
+    assert np.array_equal(bmap, last["bbox_map"].detach().cpu().numpy()), "bbox_preds is not the flattened size map"
+    # topk_index [B,N,3] int64 (:98): (ix, iy) from the flat index with the reference's divisor quirk (get_index2D
+    # divides by shape[1] = X), iz = the z arg-max that produced the bit-equal proposal centres
+    ti = last["topk_index"].cpu().numpy()
+    assert ti.dtype == np.int64
+    assert np.array_equal(ti[..., 0], g["topk_flat"] // Xh) and np.array_equal(ti[..., 1], g["topk_flat"] % Xh)
+    assert np.array_equal(ti[..., 2], np.argmax(g["hm1d"], axis=2)), "z arg-max index differs from the reference's hm1d"
     # --- proposals: indices exact
     assert np.array_equal(last["flat"].cpu().numpy(), g["topk_flat"]), "top-k flat indices differ"
     c = centers.detach().cpu().numpy()

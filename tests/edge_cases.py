@@ -37,6 +37,7 @@ def zero_batch_through_every_export(lib, dev):
     calls = {
         "fvp_heatmaps_to_cl": lambda: L.fvp_heatmaps_to_cl(p, p, 0, C.byref(g), s),
         "fvp_project_whole": lambda: L.fvp_project_whole(p, p, ip, p, p, p, X, Y, Z, 0, C.byref(g), p, p, s),
+        "fvp_project_columns": lambda: L.fvp_project_columns(p, p, ip, p, p, p, X, Y, Z, 0, C.byref(g), ip, N, p, s),
         "fvp_zmax": lambda: L.fvp_zmax(p, p, 0, Z, s),
         "fvp_person_boxes": lambda: L.fvp_person_boxes(p, 0, p, e.fine_cube, ip, p, s),
         "fvp_project_individual": lambda: L.fvp_project_individual(p, p, ip, ip, None, ip, p, p, p, ip, Cn, 0, C.byref(g), p, s),

@@ -28,11 +28,22 @@ def build_model(case, lib):
 @pytest.mark.parametrize("case", ["tiny_g_b2_all", "tiny_u_b3_thr"])
 def test_pipeline_matches_reference_golden(case, emu_lib):
     model, cfg, cams, seq, rt, heat, meta = build_model(case, emu_lib)
+    g = load_golden(case)
+    # default forward: the whole-space cubes are never materialised (fvp_project_columns feeds C2CNet)
     with torch.no_grad():
         fused, planes, centers, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+    assert model.engine.last["cubes"] is None
     report = {}
-    check_outputs(case, load_golden(case), fused, planes, centers, model.engine, report)
+    check_outputs(case, g, fused, planes, centers, model.engine, report)
     print(report)
+    feat1d = model.engine.last["feat1d"].clone()
+    # materialising forward: cubes bit-equal to the reference, and everything downstream identical to the default
+    model.engine.keep_hdn_cubes = True
+    with torch.no_grad():
+        f2, p2, c2, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+    check_outputs(case, g, f2, p2, c2, model.engine)
+    assert torch.equal(model.engine.last["feat1d"], feat1d)
+    assert torch.equal(fused, f2) and torch.equal(planes, p2) and torch.equal(centers, c2)
 
 
 def test_materialised_path_equals_fused_path(emu_lib):

@@ -38,7 +38,17 @@ def test_golden_case(case):
     assert loss is None and hm.shape == heat.shape
     report = {}
     try:
-        check_outputs(case, load_golden(case), fused, planes, centers, model.engine, report)
+        g = load_golden(case)
+        assert model.engine.last["cubes"] is None          # default forward: no [B,J,X,Y,Z] cubes (fvp_project_columns)
+        check_outputs(case, g, fused, planes, centers, model.engine, report)
+        feat1d = model.engine.last["feat1d"].clone()
+        model.engine.keep_hdn_cubes = True                 # materialising forward: cubes checked, same bits downstream
+        with torch.no_grad():
+            f2, p2, c2, _, _ = model(meta=meta, input_heatmaps=heat.to(DEV), cameras=cams, resize_transform=rt.to(DEV))
+        torch.cuda.synchronize()
+        check_outputs(case, g, f2, p2, c2, model.engine)
+        assert torch.equal(model.engine.last["feat1d"], feat1d)
+        assert torch.equal(fused, f2) and torch.equal(planes, p2) and torch.equal(centers, c2)
     finally:
         os.makedirs(os.path.dirname(REPORT), exist_ok=True)
         with open(REPORT, "a") as f:
