@@ -208,7 +208,7 @@ def mpjpe_vs_reference(dev):
     from cases import make_inputs, make_weights
     from faster_voxelpose_amd.models import faster_voxelpose as FV
     out = {}
-    for case in ("panoptic_c_b2_thr", "shelf_c_b1_thr"):
+    for case in ("panoptic_c_b2_thr", "shelf_c_b1_thr", "campus_c_b2_thr"):
         cfg, cams, seq, rt, heat, meta, _ = make_inputs(case, device=dev)
         g = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
         model = FV.get(cfg).to(dev)
@@ -219,6 +219,18 @@ def mpjpe_vs_reference(dev):
         d = np.linalg.norm((fused[..., :3].cpu().numpy() - g["fused_poses"][..., :3])[v], axis=-1)
         out[case] = {"mean": float(d.mean()), "max": float(d.max()), "joints": int(d.size),
                      "reference_fp32_vs_fp64_floor_max": float(g["margins"][5])}
+        if case.startswith("campus"):
+            # Campus: the reference's own fp32 result is 1e-3 .. 2e-3 mm from its float64 evaluation on every person, so
+            # the figure that says something is the build's distance to the float64 evaluation relative to the reference's
+            f3 = fused[..., :3].cpu().numpy().astype(np.float64)
+            d64 = np.linalg.norm(f3 - g["floor_fused"], axis=-1)
+            pfl = np.linalg.norm(g["fused_poses"][..., :3].astype(np.float64) - g["floor_fused"], axis=-1).max(axis=-1)
+            out[case].update(max_vs_fp64=float(d64[v].max()),
+                             worst_build_vs_fp64_over_reference_vs_fp64=float((d64.max(axis=-1) / pfl)[v].max()),
+                             worst_build_vs_ref32_over_reference_vs_fp64=float(
+                                 (np.linalg.norm(f3 - g["fused_poses"][..., :3], axis=-1).max(axis=-1) / pfl)[v].max()),
+                             bar="tests/common.py FLOOR_RULE: ratios <= 1.5 / 2.0 (1e-3 mm is below the reference's own "
+                                 "fp32 reproducibility on this shape)")
     try:
         import seed_sweep                                   # tests/golden: >= 10 consecutive seeds per shape
         out.update(seed_sweep.replay_all(dev))

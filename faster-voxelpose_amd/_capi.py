@@ -50,6 +50,7 @@ _G = C.POINTER(FvpGeom)
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/fvp.h 1:1
 SIGNATURES = {
     "fvp_version": [],
+    "fvp_diag_build": [],
     "fvp_sizeof": [_I],
     "fvp_error_string": [_I],
     "fvp_heatmaps_to_cl": [_P, _P, _I, _G, _P],

@@ -788,8 +788,8 @@ struct BbSwitches {
   int bn_cap;           // FVP_BB_DMA_BN: 128-cout tiles only
   bool no_fuse_final;   // FVP_BB_NO_FUSE_FINAL: heatmap layer as its own launch
   static BbSwitches read() {
-    const char* bn = getenv("FVP_BB_DMA_BN");
-    return {getenv("FVP_BB_NO_BIG") != nullptr, bn ? atoi(bn) : 256, getenv("FVP_BB_NO_FUSE_FINAL") != nullptr};
+    const char* bn = fvp::diag_env("FVP_BB_DMA_BN");
+    return {fvp::diag_env("FVP_BB_NO_BIG") != nullptr, bn ? atoi(bn) : 256, fvp::diag_env("FVP_BB_NO_FUSE_FINAL") != nullptr};
   }
 };
 

@@ -72,6 +72,7 @@ static void drain() {
 using namespace fvp;
 
 extern "C" int fvp_version(void) { return FVP_ABI_VERSION; }
+extern "C" int fvp_diag_build(void) { return FVP_DIAG; }
 
 extern "C" int fvp_sizeof(int what) {
   return what == 0 ? int(sizeof(FvpGeom)) : what == 1 ? int(sizeof(FvpConvOp)) : what == 2 ? int(sizeof(FvpBbOp)) : FVP_EINVAL;

@@ -10,7 +10,27 @@
 #define FVP_OPAQUE(x) asm volatile("" : "+s"(x))
 #endif
 
+// The shipped library reads NO environment variable.  Every kernel-selection, tuning and ablation switch documented in
+// DESIGN.md exists only in the diagnostics build (-DFVP_DIAG=1 -> tests/diag/libfvp_hip_diag.so, loaded by tests and
+// tools, never by the package): in the product every switch has its default value and the ablation masks handed to the
+// kernels are 0, so a stray variable in a user's shell cannot change a result.
+#ifndef FVP_DIAG
+#define FVP_DIAG 0
+#endif
+#if FVP_DIAG
+#include <cstdlib>
+#endif
+
 namespace fvp {
+
+inline const char* diag_env(const char* name) {
+#if FVP_DIAG
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // Conv epilogue affine (bias, then eval-BatchNorm scale/shift) with a pinned operation order so
 // that every kernel variant produces the same bits: one rounding for acc + bias, one fma.

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "fvp_asm.h"
 #include "fvp_common.h"
 
 // waves per SIMD the 1x1 / transposed-conv kernels are compiled for: they are HBM-bound, three waves (<= 168 VGPRs)
@@ -42,7 +43,7 @@ constexpr int kStageS = 8;   // same for the 4-byte generic path
 // 0 <= x < 2^32/d; d == 1 is flagged by magic == 0).  Runtime integer division costs ~40 VALU
 // instructions on gfx950; the index arithmetic of a workgroup used to contain ~90 of them.
 __device__ __forceinline__ int fdiv(int x, unsigned magic) { return magic ? int(__umulhi(unsigned(x), magic)) : x; }
-typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef fvp_i32x4 i32x4;
 
 static unsigned make_magic(int d) { return d <= 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; }
 
@@ -682,11 +683,7 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
   // fails the range check: the hardware writes zeros (tools/micro/buflds.hip).  Only a ragged last chunk (cin or cinp not
   // a multiple of CC) masks per item.
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-#if !defined(HIPEMU)
-  const unsigned lds0 = unsigned(size_t((const __attribute__((address_space(3))) float*)smem));
-#else
-  const unsigned lds0 = 0;
-#endif
+  const unsigned lds0 = FVP_LDS_BYTE_ADDRESS(smem);
   auto make_rsrc = [](const float* p) {
     const unsigned long long b = reinterpret_cast<unsigned long long>(p);
     i32x4 rs;
@@ -699,25 +696,17 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
   const i32x4 rs_in = make_rsrc(src_tile), rs_w = make_rsrc(wts);
   constexpr int QPRW = CBW / 4;                       // 16-byte quads per packed weight row
   constexpr int RPI = 256 / QPRW;                     // weight rows between item j and item j + 1 of a lane
+  static_assert(256 % QPRW == 0, "item j + 1 of a lane must lie a whole number of packed weight rows further (CB in {1,2,4})");
   const int wit0 = wave * 64 + lane;
   const int wrow0 = wit0 / QPRW;
   const unsigned vw0 = unsigned(wrow0 * a.wrow + 4 * (wit0 % QPRW)) * 4u;
-  auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) {
-#if defined(HIPEMU)
-    hipemu_buffer_load_lds16(smem, la, vo, rs[0], rs[1], rs[2], so);
-#else
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :
-                 : "s"(la), "v"(vo), "s"(rs), "s"(so)
-                 : "memory", "m0");
-#endif
-  };
+  auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) { asm_buffer_load_lds16(la, vo, rs, so); };
   auto stage_buf = [&](int k, int buf) {
     const int c0 = k * a.CC;
     const unsigned la_x = lds0 + 4u * unsigned(4 + buf * buf_sz + wave_s * 256);
     const unsigned la_w = la_x + 4u * unsigned(xs_sz);
     const unsigned so_in = unsigned(c0) * unsigned(HW) * 4u;
-    const bool ragged = c0 + a.CC > a.cin || c0 + a.CC > a.cinp;      // uniform: only ever the last chunk
+    const bool ragged = c0 + a.CC > a.cin || c0 + a.CC > a.cinp;      // uniform: the trailing chunk(s) that reach past cin / cinp
 #pragma unroll
     for (int j = 0; j < kMaxIn; ++j) {
       const int g = wave + 4 * j;
@@ -1035,8 +1024,17 @@ static int dispatch_conv(int kh, int kw, int CB, int PB, const ConvArgs& a, dim3
   return FVP_ELIMIT;
 }
 
+// The LDS-DMA of k_conv_dma / k_conv_wino addresses a work unit's input and weights with 32-bit BYTE offsets against a
+// raw buffer descriptor whose num_records is 0x7ffffff0: per-lane offset (up to (TN + 1) planes of the plane group) plus
+// the scalar chunk offset (up to one plane).  An offset that wrapped or failed the range check would make the hardware
+// write zeros - a silently wrong result - so shapes outside the range are refused with FVP_ELIMIT here.
+static bool buf_dma_range_ok(int TN, int cin, int h, int w, double weight_floats) {
+  const double lim = double(0x7ffffff0u);
+  return (double(TN) + 2.0) * cin * h * w * 4.0 < lim && weight_floats * 4.0 < lim;
+}
+
 static size_t env_size(const char* name, size_t dflt) {
-  const char* v = getenv(name);
+  const char* v = fvp::diag_env(name);
   return v ? size_t(atol(v)) : dflt;
 }
 // tuning knobs (diagnostics): FVP_CONV_LDS_KB, FVP_CONV_ABLATE, FVP_CONV_PB
@@ -1167,6 +1165,7 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   if (3 * slot + (resw ? resw_bytes : 0) + 64 + epi_bytes > budget || ni > 4) return FVP_ELIMIT;
   a.CC = CC;
   a.wino_ni = ni;
+  if (!buf_dma_range_ok(TN, op.cin, op.h, op.w, double(op.cinp) * op.coutp * 16)) return FVP_ELIMIT;
   a.m_qpr = make_magic(op.w / 4 + 1);
   a.m_rpc = make_magic(TN * (a.TH + 2));
   a.m_thp = make_magic(a.TH + 2);
@@ -1184,7 +1183,7 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   a.dbg = dbg;
   int rc = (WC * WT == 4) ? launch_wino<1, 4>(a, grid, lds, s, false)
                           : (WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false));
-  if (dbg && getenv("FVP_WINO_TIMING_PRINT")) {
+  if (dbg && fvp::diag_env("FVP_WINO_TIMING_PRINT")) {
     unsigned long long h[32];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -1375,6 +1374,9 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
     while (CC > 8 && op.cinp % CC) CC -= 8;
   }
   a.CC = CC;
+  if (a.dma && !buf_dma_range_ok(a.TN, op.cin, op.h, op.w, double(op.cinp) * kh * kt * a.wrow)) return FVP_ELIMIT;
+  // stage_buf packs an item's channel-in-chunk into 8 bits
+  if (a.dma && CC > 255) return FVP_ELIMIT;
   a.m_qpr = make_magic(a.dma ? a.TW / 4 + 1 : a.TW / 4);
   a.m_rpc = make_magic(a.TN * (a.TH + kh - 1));
   a.m_thp = make_magic(a.TH + kh - 1);

@@ -397,7 +397,7 @@ extern "C" int fvp_conv_stack_run_fused_1d(const FvpConvOp* ops, int nops, const
   a.L = ops[0].w;
   total = (total + 64 + 3) & ~3;                     // slack for channel-padding rows; keeps the weight buffers 16-B aligned
   a.lds_floats = total;
-  static const int kAblate1d = getenv("FVP_C1D_ABLATE") ? atoi(getenv("FVP_C1D_ABLATE")) : 0;
+  static const int kAblate1d = fvp::diag_env("FVP_C1D_ABLATE") ? atoi(fvp::diag_env("FVP_C1D_ABLATE")) : 0;
   a.ablate = kAblate1d;
   a.params = params;
   a.in = in;

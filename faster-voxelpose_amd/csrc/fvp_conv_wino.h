@@ -78,20 +78,17 @@ namespace fvp {
 // source says: s_waitcnt vmcnt(n) counted per chunk + s_barrier.
 // The LDS destination is given as (array, float index): the generic -> LDS cast of the bare array folds to a constant; a
 // cast of a pointer VARIABLE makes hipcc emit a null check that this compiler version mis-selects ("Illegal instruction").
-__device__ __forceinline__ void lds_dma16(const float* g, const float* lds, int idx, int aux) {
-#if FVP_WINO_ASM_DMA && !defined(HIPEMU)
-  const unsigned base = unsigned(size_t((const __attribute__((address_space(3))) float*)lds));
-  const unsigned la = __builtin_amdgcn_readfirstlane(base + 4u * unsigned(idx));
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory", "m0");
+#if FVP_WINO_ASM_DMA
+#define FVP_WINO_LDS_DMA16(g, lds, idx, aux) \
+  asm_global_load_lds16(g, __builtin_amdgcn_readfirstlane(FVP_LDS_BYTE_ADDRESS(lds) + 4u * unsigned(idx)))
 #else
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)(const_cast<float*>(lds) + idx), 16, 0, FVP_WINO_IN_AUX);
+#define FVP_WINO_LDS_DMA16(g, lds, idx, aux)                                                          \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),                \
+                                   (__attribute__((address_space(3))) void*)(const_cast<float*>(lds) + (idx)), 16, 0, aux)
 #endif
-}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Column pass of the input transform on register pairs E = (t0, t3), M = (t1, t2):
 //   v03 = (t0 - t2, t1 - t3)   v12 = (t1 + t2, t2 - t1)
@@ -203,11 +200,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // and the select are gone too.
   constexpr unsigned kOOB = 0x80000000u;             // + any chunk offset (< 2^31) still fails the range check
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-#if defined(HIPEMU)
-  const unsigned lds0 = 0;                           // (emulator: LDS addresses are byte offsets from smem)
-#else
-  const unsigned lds0 = unsigned(size_t((const __attribute__((address_space(3))) float*)smem));
-#endif
+  const unsigned lds0 = FVP_LDS_BYTE_ADDRESS(smem);
   unsigned voff[kMaxIn];                             // this lane's input items: byte offset from (unit base - one row), or kOOB
   const unsigned woffb = unsigned(woff0) * 4u;       // this lane's weight item 0 (bytes from the unit's cout block, chunk 0)
   i32x4 rs_in = {0, 0, 0x7ffffff0, 0x00020000}, rs_w = {0, 0, 0x7ffffff0, 0x00020000};   // raw buffers, stride 0
@@ -237,16 +230,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       }
     }
   };
-  auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) {
-#if defined(HIPEMU)
-    hipemu_buffer_load_lds16(smem, la, vo, rs[0], rs[1], rs[2], so);
-#else
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :
-                 : "s"(la), "v"(vo), "s"(rs), "s"(so)
-                 : "memory", "m0");
-#endif
-  };
+  auto buf_dma16 = [&](unsigned vo, const i32x4& rs, unsigned so, unsigned la) { asm_buffer_load_lds16(la, vo, rs, so); };
   // every wave issues exactly nps DMA instructions per chunk (counted s_waitcnt vmcnt below)
   auto stage = [&](int k, int boff) {
     const unsigned so_in = unsigned(k) * unsigned(in_step) * 4u;
@@ -309,14 +293,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       if (j < a.wino_ni) {
         const int g = wave + NWV * j;
         const float* src = ((okmask >> j) & 1u) ? bk + rel_off[j] : a.zeros;
-        lds_dma16(src, smem, 4 + boff + g * 256, FVP_WINO_IN_AUX);
+        FVP_WINO_LDS_DMA16(src, smem, 4 + boff + g * 256, FVP_WINO_IN_AUX);
       }
     }
     const float* wk = gwbase + size_t(k) * w_step + woff0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int g = wave + NWV * j;
-      lds_dma16(wk + j * wdj, smem, 4 + boff + xs_sz + g * 256, 0);
+      FVP_WINO_LDS_DMA16(wk + j * wdj, smem, 4 + boff + xs_sz + g * 256, 0);
     }
   };
 #endif
@@ -390,7 +374,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     const int rounds = (a.cinp * CBW * 4) / (NWV * 64);
     for (int j = 0; j < rounds; ++j) {
       const int g = wave + NWV * j;
-      lds_dma16(a.wts + size_t(g * 64 + lane) * 4, smem, 4 + 3 * buf_sz + g * 256, 0);
+      FVP_WINO_LDS_DMA16(a.wts + size_t(g * 64 + lane) * 4, smem, 4 + 3 * buf_sz + g * 256, 0);
     }
     if (!dma) wait_vmcnt(0);
   }
@@ -420,7 +404,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
 #define FVP_TS(x)
 #endif
   int cur_off = 0;
-  int st_pending = 0;                                // stores of the previous unit's epilogue that may still be in flight
+  int st_pending = 0;                                // 1: the previous unit's epilogue drained the DMA queue (its stores may still be in flight)
   fetch_a(0, wchunk(smem + 4, 0), 0);
   fetch_d(smem + 4, 0, WP);
   while (true) {
@@ -496,9 +480,10 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
         // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
         if (dma) {
-          if constexpr (kFirst || !FVP_WINO_ZERO_C) {  // a unit's first chunk: the previous epilogue's stores may count in
-            const int keep = (more ? nps : 0) + st_pending;
-            wait_vmcnt(keep < 63 ? keep : 63);
+          if constexpr (kFirst || !FVP_WINO_ZERO_C) {
+            // a unit's first chunk: behind an epilogue that drained the DMA queue (st_pending, see there) the chunk this
+            // barrier guards has already landed and the epilogue's stores may stay in flight: no vmcnt wait at all
+            if (!st_pending) wait_vmcnt_small(more ? nps : 0);
             st_pending = 0;
           } else {
             wait_vmcnt_small(more ? nps : 0);          // nps <= 8: a handful of scalar instructions instead of ~30
@@ -602,8 +587,13 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // ONE wait for all residual loads.  The stores below are conditional (masked tiles), so behind the first of them the
   // compiler's counter no longer knows how many younger operations are in the queue and every later use of a loaded
   // value would get a full vmcnt(0) - i.e. wait for the stores issued so far.
+  // The same wait (taken by the kernels without a residual too) is what makes "stores stay in flight" safe BY
+  // CONSTRUCTION: the only DMA chunk still in the in-order vmcnt queue here is the one requested at the top of this
+  // unit's last chunk - the chunk the NEXT unit's first barrier has to see landed.  After vmcnt(0) it has landed, so
+  // that barrier needs no vmcnt wait at all, whatever the number of store instructions hipcc emits below (round 3
+  // counted them - 16 + 8 - and a miscount would have let the barrier pass early: ADVICE round 3).
   __builtin_amdgcn_sched_barrier(0);
-  if (HAS_RES) wait_vmcnt(0);
+  if (HAS_RES || (FVP_WINO_STORES_IN_FLIGHT && dma)) wait_vmcnt(0);
   __builtin_amdgcn_sched_barrier(0);
   // every P2PNet / CenterNet layer on this kernel is BN (+ residual) -> ReLU: that order gets its own copy of the loop (as
   // run-time flags the two selects per value were a quarter of the epilogue's instructions)
@@ -662,17 +652,9 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   const bool fast = FVP_WINO_EPI_FAST && relu && !res_after && (a.cout & 31) == 0 && !(FVP_WINO_DIAG && (a.ablate & 32));
   if (fast) finalize(std::integral_constant<bool, true>{});
   else finalize(std::integral_constant<bool, false>{});
-  // The stores above sit in the (in-order) vmcnt queue BEHIND chunk 1 of the next unit, which was requested before them:
-  // the first chunk barrier of the next unit lets them stay in flight instead of waiting for their round trip.  Only
-  // when their number is KNOWN: in the fast form a wave issues all of them iff any of its lanes owns a tile (a store
-  // block with an empty exec mask may be branched over), and a wave's first lane owns its first tile - tiles, rows and
-  // planes grow with the lane.  Counting stores that were not issued would let the wait pass before chunk 1 has landed.
-#if defined(HIPEMU)
-  st_pending = 0;
-#else
-  st_pending = (FVP_WINO_STORES_IN_FLIGHT && fast && __builtin_amdgcn_readfirstlane(int(tile_ok)) != 0)
-                   ? 16 + (a.pool_dst ? 8 : 0) : 0;
-#endif
+  // The stores above may stay in flight across the next unit's first chunk barrier: the chunk that barrier guards has
+  // landed (vmcnt(0) above), so its wait is lifted to the counter's maximum - no dependence on how many stores exist.
+  st_pending = (FVP_WINO_STORES_IN_FLIGHT && dma) ? 1 : 0;
   }
 #if !FVP_WINO_ZERO_C
 #pragma unroll

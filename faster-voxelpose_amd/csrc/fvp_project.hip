@@ -687,7 +687,7 @@ extern "C" int fvp_project_whole(const float* heat_cl, const float* cams, const 
   if (B == 0) return 0;
   const int cpb = 256 / Z;
   ProfScope ps(FVP_K_PROJECT_WHOLE, as_stream(s));
-  static const bool no_quad = getenv("FVP_WHOLE_NO_QUAD") != nullptr;
+  static const bool no_quad = fvp::diag_env("FVP_WHOLE_NO_QUAD") != nullptr;
   const int nvl = ceil_div(g->JP, 16);
   if (!no_quad && nvl <= 2) {
     const int nblk = ceil_div(X * Y, cpb);
@@ -801,22 +801,22 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   ProfScope ps(FVP_K_PROJECT_TRIPLANE, as_stream(s));
   // default: heatmap footprint staged in LDS (fvp_project_lds.h); FVP_TRIPLANE_GATHER=1 selects the first fused
   // kernel (every tap through the texture path) for comparison
-  static const bool gather = getenv("FVP_TRIPLANE_GATHER") != nullptr;
+  static const bool gather = fvp::diag_env("FVP_TRIPLANE_GATHER") != nullptr;
   // FVP_TRIPLANE_QUAD=1: the round-2 form of the LDS-staged kernel (four lanes per voxel) instead of one lane per voxel
-  const bool quad_form = getenv("FVP_TRIPLANE_QUAD") != nullptr;            // read per call: tests switch it
+  const bool quad_form = fvp::diag_env("FVP_TRIPLANE_QUAD") != nullptr;            // read per call: tests switch it
   // diagnostics (wrong results): 1 no sampling, 2 no tile DMA, 4 no plane maxima, 8 no global-gather fallback
-  static const int tri_ablate_env = getenv("FVP_TRI_ABLATE") ? atoi(getenv("FVP_TRI_ABLATE")) : 0;
+  static const int tri_ablate_env = fvp::diag_env("FVP_TRI_ABLATE") ? atoi(fvp::diag_env("FVP_TRI_ABLATE")) : 0;
   // bit 16 (NOT a diagnostic: results are identical either way): rectangles that fit the two tiles together are
   // staged across both when their turn comes instead of being gathered from global memory.  On for the
   // lane-per-voxel form (its gather reads 64 lines per instruction), off for the quad form (measured 495 -> 515 us:
   // the quad form's gather runs on the otherwise idle texture path beside the LDS reads of the staged rectangles).
   // FVP_TRI_TWO_TILE=0/1 overrides.
-  const char* tt_env = getenv("FVP_TRI_TWO_TILE");
+  const char* tt_env = fvp::diag_env("FVP_TRI_TWO_TILE");
   const bool lane_form = !gather && !quad_form && g->JP <= 20 && g->JP != 16;
   const int tri_ablate = (tri_ablate_env & ~16) | ((tt_env ? atoi(tt_env) != 0 : lane_form) ? 16 : 0);
   // tests: FVP_TRI_CAP_PX lowers the rectangle size the kernel treats as fitting a tile (the allocation is unchanged),
   // so that one-tile, two-tile and global-gather rectangles all occur on small fixtures; read per call
-  auto cap_lim = [](int cap) { const char* e = getenv("FVP_TRI_CAP_PX"); const int v = e ? atoi(e) : cap; return v > 0 && v < cap ? v : cap; };
+  auto cap_lim = [](int cap) { const char* e = fvp::diag_env("FVP_TRI_CAP_PX"); const int v = e ? atoi(e) : cap; return v > 0 && v < cap ? v : cap; };
   const int F0 = fine_grid ? fine[0] : 0, F1 = fine_grid ? fine[1] : 0, F2 = fine_grid ? fine[2] : 0;
   const int nbx = ceil_div(C, kBX), nby = ceil_div(C, kBY);
   // two tiles per workgroup, two workgroups (512 threads, <= 128 VGPRs) per CU: 4 x 36 KB + state
@@ -826,7 +826,7 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   // lane and 16-deep blocks): Campus 222 -> 160 us, Shelf 756 -> 714 us for 80 / 40 people.  JP = 16 (Panoptic) stays
   // on the quad form (490 vs 616 us: more than half of its rectangles exceed a tile and are gathered, which the quad
   // form does with 4x fewer cache lines per instruction); JP 24 .. 32 would spill.  FVP_TRIPLANE_LANE=1 forces it.
-  static const bool force_lane = getenv("FVP_TRIPLANE_LANE") != nullptr;
+  static const bool force_lane = fvp::diag_env("FVP_TRIPLANE_LANE") != nullptr;
   if (lane_form || (force_lane && !gather && g->JP <= 20)) {
     const int lq = (g->JP / 4) | 1;                                           // tile pixel pitch in quads (odd)
     const int cap_px = int((36 * 1024) / (size_t(lq) * 16));

@@ -44,9 +44,9 @@ class PoseResNet(ParamTree):
         self._declare()
         self.__dict__["_dirty"] = True
         self.__dict__["_plans"] = {}
-        # per-(image size, batch) choice of the conv tile configuration by measurement (fvp_bb_tune); FVP_BB_NO_TUNE=1
-        # keeps the built-in heuristic
-        self.__dict__["autotune"] = not os.environ.get("FVP_BB_NO_TUNE")
+        # per-(image size, batch) choice of the conv tile configuration by measurement (fvp_bb_tune); set
+        # ``model.autotune = False`` to keep the built-in heuristic
+        self.__dict__["autotune"] = True
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_dirty())
 
     # ---- parameters (registration order = the reference's module order) ------------------------------------------

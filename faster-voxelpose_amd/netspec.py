@@ -59,6 +59,11 @@ class ParamTree(nn.Module):
         raise RuntimeError("ParamTree holds parameters only")
 
 
+# Set by tests that load the diagnostics build with FVP_WINO_GENERIC=1 (masked Winograd tiles for rows that do not
+# divide the workgroup tile); the shipped library never takes that path, and nothing here reads the environment.
+WINO_GENERIC = False
+
+
 def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None):
     """3x3 layers the F(2x2,3x3) kernel covers (the same rule as wino_tiling() in
     csrc/fvp_conv.hip): decided from the layer shape alone, never from the batch."""
@@ -66,7 +71,7 @@ def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None):
         return False
     if cin is not None and cin != cinp:          # whole channel chunks only (no padded input channels)
         return False
-    if w & (w - 1) and os.environ.get("FVP_WINO_GENERIC", "0") != "1":
+    if w & (w - 1) and not WINO_GENERIC:
         return False                             # rows that do not divide the workgroup tile: direct kernel by default
     return w // 2 <= (128 if coutp == 32 else 64)   # a tile row fits the workgroup's 16 * WT tiles
 

@@ -48,6 +48,10 @@ typedef struct FvpGeom {
 } FvpGeom;
 
 int fvp_version(void);
+/* 0 for the shipped library, which reads NO environment variable; 1 for the diagnostics build (-DFVP_DIAG=1,
+ * tests/diag/libfvp_hip_diag.so - test / tool infrastructure) in which the kernel-selection, tuning and ablation
+ * switches of DESIGN.md section 6 (FVP_* environment variables) are honoured. */
+int fvp_diag_build(void);
 /* sizeof(FvpGeom) (what = 0) / sizeof(FvpConvOp) (what = 1) as compiled into the library: lets a
  * binding check its struct mirrors before passing them. */
 int fvp_sizeof(int what);

@@ -25,6 +25,38 @@ FLOOR_FACTOR = 3.0
 FP64_EXCEPTIONS = {"tiny_u_b3_thr": 3e-3, "campus_u_b2_all": 4e-3, "panoptic_u_b1_all": 6e-3}
 
 
+# Conditioned fixtures on which the REFERENCE's fp32 output is itself further than 1e-3 mm from its own float64 evaluation,
+# so "within 1e-3 mm of the reference's fp32 result" is below what the reference reproduces.  Campus: 3 views, world
+# coordinates of 4 .. 7.5 m (one fp32 ulp = 4.9e-4 mm), blurry 360 x 288 images -> every person of every seed has a
+# reference fp32-vs-fp64 distance of 0.8e-3 .. 2.0e-3 mm (tests/golden/find_conditioned.py, cases.py).  The bar asserted
+# there, per valid proposal p with pfloor_p = max_j |ref32 - ref64| (the reference's own error on that person):
+#     max_j |build - ref64| <= K64 * pfloor_p     the build is at most 1.5x as far from the exact answer as the reference
+#     max_j |build - ref32| <= K32 * pfloor_p     and within twice the reference's own error of the reference's fp32 result
+# (tighter than the triangle inequality K64 + 1 = 2.5, and than the seed sweep's R2 factor 3).  Fixed before the first GPU
+# run of this fixture; the CPU emulation of the kernels gave worst ratios 1.26 / 1.71 (9 proposals, pfloor 0.96e-3 .. 1.97e-3,
+# |build - ref32| max 2.0e-3 mm: the literal 1e-3 mm bar is NOT met on Campus, by the reference's fp32 path either).
+FLOOR_RULE = {"campus_c_b2_thr": (1.5, 2.0)}
+
+
+def floor_rule_check(case, xyz, g, report=None):
+    """Assert FLOOR_RULE[case] for joints ``xyz`` [B,N,J,3] (numpy) against the golden ``g``; returns the worst ratios."""
+    k64, k32 = FLOOR_RULE[case]
+    v = g["valid"]
+    f3 = xyz.astype(np.float64)
+    d32 = np.linalg.norm(f3 - g["fused_poses"][..., :3], axis=-1)            # [B,N,J]
+    d64 = np.linalg.norm(f3 - g["floor_fused"], axis=-1)
+    pfl = np.linalg.norm(g["fused_poses"][..., :3].astype(np.float64) - g["floor_fused"], axis=-1).max(axis=-1)   # [B,N]
+    r64 = (d64.max(axis=-1) / pfl)[v]
+    r32 = (d32.max(axis=-1) / pfl)[v]
+    if report is not None:
+        report.update(worst_ratio_vs_fp64=float(r64.max()), worst_ratio_vs_ref32=float(r32.max()),
+                      proposal_floor_min_mm=float(pfl[v].min()), proposal_floor_max_mm=float(pfl[v].max()))
+    assert pfl[v].min() > 5e-4, "fixture no longer needs the floor rule"
+    assert r64.max() <= k64 and r32.max() <= k32, \
+        f"{case}: |build-ref64| / pfloor max {r64.max():.2f} (bar {k64}), |build-ref32| / pfloor max {r32.max():.2f} (bar {k32})"
+    return float(r64.max()), float(r32.max())
+
+
 def is_conditioned(case):
     from cases import CASES
     return CASES[case][1] == "c"
@@ -124,7 +156,9 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
         report.update(case=case, max_mm_vs_ref=float(e32.max()) if e32.size else 0.0,
                       mean_mm_vs_ref=float(e32.mean()) if e32.size else 0.0,
                       max_mm_vs_fp64=float(e64.max()) if e64.size else 0.0, ref_floor_mm=floor)
-    if e32.size:
+    if case in FLOOR_RULE and e32.size:
+        floor_rule_check(case, fused[..., :3].detach().cpu().numpy(), g, report)
+    elif e32.size:
         if is_conditioned(case):
             ok = e32.max() <= BAR_MM                       # the north-star bar itself
         else:
@@ -137,7 +171,7 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
     assert np.all(f[..., :3][~v] == 0.0), "invalid proposals must have zero joints"
     np.testing.assert_allclose(f[..., 4], g["fused_poses"][..., 4], rtol=2e-4, atol=1e-6)
     pl = planes.detach().cpu().numpy()
-    tol = BAR_MM if is_conditioned(case) else max(BAR_MM, FLOOR_FACTOR * floor) * 2
+    tol = BAR_MM if (is_conditioned(case) and case not in FLOOR_RULE) else max(BAR_MM, FLOOR_FACTOR * floor) * 2
     np.testing.assert_allclose(pl, g["plane_poses"], rtol=0, atol=tol)
 
 

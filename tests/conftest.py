@@ -20,7 +20,38 @@ def emu_lib():
     import ctypes
 
     from faster_voxelpose_amd import _capi as capi
-    os.environ.setdefault("FVP_WINO_GENERIC", "1")    # read once when the library loads: lets one test cover masked tiles
+    from faster_voxelpose_amd import netspec
+    # the emulated library is a diagnostics build (-DFVP_DIAG=1): it honours the FVP_* switches.  Masked Winograd tiles
+    # (rows that do not divide the workgroup tile) are switched on for the whole emulated session so that one test covers
+    # them: read once when the library loads, mirrored on the host side by netspec.WINO_GENERIC (weight-blob layout).
+    os.environ.setdefault("FVP_WINO_GENERIC", "1")
+    netspec.WINO_GENERIC = True
     here = os.path.join(ROOT, "tests", "hipemu")
     subprocess.run([os.path.join(here, "build_emu.sh")], check=True, capture_output=True)
     return capi.bind(ctypes.CDLL(os.path.join(here, "libfvp_emu.so")))
+
+
+def _diag_path():
+    return os.path.join(ROOT, "tests", "diag", "libfvp_hip_diag.so")
+
+
+@pytest.fixture(scope="session")
+def diag_lib():
+    """The diagnostics build of the HIP library (tests/diag/build_diag.sh, -DFVP_DIAG=1) for GPU tests that flip
+    kernel-selection switches through the environment - the shipped library ignores the environment."""
+    import ctypes
+
+    import torch  # noqa: F401  (its HIP runtime first: see _capi.load)
+    from faster_voxelpose_amd import _capi as capi
+    if not os.path.isfile(_diag_path()):
+        subprocess.run([os.path.join(ROOT, "tests", "diag", "build_diag.sh")], check=True, capture_output=True)
+    lib = capi.bind(ctypes.CDLL(_diag_path()))
+    assert lib.fvp_diag_build() == 1
+    return lib
+
+
+def pytest_sessionstart(session):
+    # tools/gpu_switch_matrix.sh: the whole GPU suite on the diagnostics build, so that the FVP_* switches it sets act
+    if os.environ.get("FVP_TEST_DIAG_LIB") == "1":
+        from faster_voxelpose_amd import _capi as capi
+        capi.LIB_PATH = _diag_path()

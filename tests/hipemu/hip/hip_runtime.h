@@ -211,14 +211,23 @@ static inline void hipemu_glds(const __attribute__((address_space(1))) void* g, 
 }
 #define __builtin_amdgcn_global_load_lds hipemu_glds
 
+// ---- the product's inline-asm primitives (faster-voxelpose_amd/csrc/fvp_asm.h), emulated ----------------------------
+// LDS byte addresses are offsets from the workgroup's dynamic LDS base.
+#define FVP_ASM_PRIMITIVES_PROVIDED 1
+#define FVP_LDS_BYTE_ADDRESS(arr) unsigned((const char*)(arr) - (const char*)hipemu::dyn_smem())
+namespace fvp {
+typedef int fvp_i32x4 __attribute__((ext_vector_type(4)));
+// global_load_lds_dwordx4: lane l copies 16 bytes from its global address to LDS byte address lds_addr + 16 l
+static inline void asm_global_load_lds16(const float* g, unsigned lds_addr) {
+  memcpy(hipemu::dyn_smem() + lds_addr + size_t(hipemu::cur->lane) * 16, g, 16);
+}
 // buffer_load_dwordx4 ... offen lds (raw buffer, stride 0): lane l copies 16 bytes from base + voffset + soffset to LDS
-// offset `la` + 16 l; every dword whose offset fails the range check (offset + 4 > num_records, the SGPR offset included)
-// is written as zero - what tools/micro/buflds.hip measured on gfx950.  `la` is a byte offset from the kernel's dynamic
-// LDS base (the kernels build it from lds0 = 0 in this build).
-static inline void hipemu_buffer_load_lds16(const void* lds_base, unsigned la, unsigned vo, int rs0, int rs1, int rs2, unsigned so) {
-  const unsigned long long base = (unsigned long long)(unsigned)rs0 | ((unsigned long long)((unsigned)rs1 & 0xffffu) << 32);
-  const unsigned long long nrec = (unsigned)rs2;
-  char* dst = (char*)lds_base + la + size_t(hipemu::cur->lane) * 16;
+// byte address `la` + 16 l; every dword whose offset fails the range check (offset + 4 > num_records, the SGPR offset
+// included) is written as zero - what tools/micro/buflds.hip measured on gfx950.
+static inline void asm_buffer_load_lds16(unsigned la, unsigned vo, const fvp_i32x4& rs, unsigned so) {
+  const unsigned long long base = (unsigned long long)(unsigned)rs[0] | ((unsigned long long)((unsigned)rs[1] & 0xffffu) << 32);
+  const unsigned long long nrec = (unsigned)rs[2];
+  char* dst = hipemu::dyn_smem() + la + size_t(hipemu::cur->lane) * 16;
   for (int d = 0; d < 4; ++d) {
     const unsigned long long off = (unsigned long long)vo + so + 4ull * d;
     float v = 0.0f;
@@ -226,6 +235,7 @@ static inline void hipemu_buffer_load_lds16(const void* lds_base, unsigned la, u
     memcpy(dst + 4 * d, &v, 4);
   }
 }
+}  // namespace fvp
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)

@@ -31,6 +31,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.fvp_version() == capi.ABI_VERSION
     assert lib.fvp_sizeof(0) == ctypes.sizeof(capi.FvpGeom) and lib.fvp_sizeof(1) == ctypes.sizeof(capi.FvpConvOp)
     assert b"invalid argument" in lib.fvp_error_string(10001)
+    assert lib.fvp_diag_build() == 0      # the shipped library is not the diagnostics build
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """Every FVP_* switch lives behind -DFVP_DIAG=1 (tests/diag/libfvp_hip_diag.so): the product's objects do not even
+    import getenv, and none of its sources calls it outside fvp::diag_env."""
+    import subprocess
+    csrc = os.path.join(ROOT, "faster-voxelpose_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(csrc, f)).read()
+            uses = re.findall(r"(?<![\w:])(?:std::)?getenv\s*\(", text)
+            assert len(uses) == (1 if f == "fvp_common.h" else 0), f"{f}: getenv outside fvp::diag_env"
+    if os.path.isfile(capi.LIB_PATH):
+        syms = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+        assert "getenv" not in syms, "libfvp_hip.so imports getenv"
 
 
 def test_product_refuses_cpu_device():

@@ -226,7 +226,9 @@ def _worker_real_path(rank, world, port, q):
     import subprocess
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("FVP_WINO_GENERIC", "1")
+    os.environ.setdefault("FVP_WINO_GENERIC", "1")     # (the emulated library is a -DFVP_DIAG=1 build, see tests/conftest.py)
+    from faster_voxelpose_amd import netspec
+    netspec.WINO_GENERIC = True
     for p_ in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")):
         if p_ not in sys.path:
             sys.path.insert(0, p_)

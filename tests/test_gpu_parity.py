@@ -64,6 +64,9 @@ def test_float_parity_seed_sweep(name):
       R1  joints whose own reference fp32-vs-fp64 floor is <= 4e-4 mm: |build - ref32| <= 1e-3 mm - asserted with zero
           exceptions for panoptic_b8 and panoptic128_b1, reported for Shelf / Campus;
       R1p joints of proposals whose worst-joint floor is <= 4e-4 mm: <= 1e-3 mm, every shape;
+      R1q joints with floor <= 4e-4 mm in proposals whose worst-joint floor is <= 1e-3 mm: <= 1e-3 mm - asserted for
+          Panoptic, jln128 and Shelf (round 4), reported for Campus, whose asserted float bar is the conditioned fixture
+          campus_c_b2_thr (tests/common.py FLOOR_RULE);
       R2  every joint: |build - ref32| <= 3 x max(its proposal's floor, 4e-4) - never noisier than the reference;
       proposal centres bit-equal; the overall fraction within 1e-3 mm goes to the parity report."""
     import seed_sweep as SW
@@ -78,6 +81,8 @@ def test_float_parity_seed_sweep(name):
     if name in ("panoptic_b8", "panoptic128_b1"):
         assert s["violations_where_floor_le_4e-4"] == 0, s                       # R1
     assert s["violations_in_proposals_with_floor_le_4e-4"] == 0, s               # R1p
+    if name != "campus_b2":
+        assert s["violations_r1q"] == 0 and s["joints_r1q"] > 300, s             # R1q (Shelf: 910 joints in round 3)
     assert name == "campus_b2" or s["joints_of_proposals_with_floor_le_4e-4"] > 300
     assert s["worst_err_over_proposal_floor"] <= 3.0, s                          # R2
 
@@ -481,7 +486,7 @@ def test_backbone_full_image_size_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_backbone_tile_shapes_give_identical_heatmaps(monkeypatch):
+def test_backbone_tile_shapes_give_identical_heatmaps(monkeypatch, diag_lib):
     """The LDS-DMA conv kernel with 256-cout tiles where they fill the chip (default), with 128-cout tiles everywhere
     and at a batch that leaves partial pixel tiles / partial XCD groups: the tile shape changes neither the k order
     nor the MFMA shape, so the heatmaps are bit-identical.  The register-staged 128 x 128 kernel walks k tap-major
@@ -489,11 +494,15 @@ def test_backbone_tile_shapes_give_identical_heatmaps(monkeypatch):
     from faster_voxelpose_amd.core import config as CFG
     from faster_voxelpose_amd.models import resnet as RN
     cfg = CFG.default_config()
-    m = RN.get(cfg).to("cuda:0")
+    # the switches below are honoured by the diagnostics build only (tests/diag; the shipped library reads no environment)
+    m = RN.PoseResNet(cfg, _lib=diag_lib).to("cuda:0")
     m.load_state_dict(S.fill_backbone_state_dict(m.state_dict(), seed=5))
     x = torch.from_numpy(np.random.default_rng(2).random((3, 3, 160, 224), dtype=np.float32)).cuda()
     with torch.no_grad():
         y0 = m(x).clone()
+        mp = RN.get(cfg).to("cuda:0")                      # the product library: same bits as the diagnostics build's default
+        mp.load_state_dict(m.state_dict())
+        assert torch.equal(mp(x), y0)
         monkeypatch.setenv("FVP_BB_DMA_BN", "128")
         y1 = m(x).clone()
         monkeypatch.delenv("FVP_BB_DMA_BN")

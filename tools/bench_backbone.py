@@ -14,8 +14,9 @@ from faster_voxelpose_amd.core import config as CFG  # noqa: E402
 from faster_voxelpose_amd.models import resnet as RN  # noqa: E402
 from faster_voxelpose_amd import _capi as _capi0  # noqa: E402
 
-if os.environ.get("FVP_LIB"):          # diagnostics only: a variant built by tools/build_variant.sh
-    _capi0.LIB_PATH = os.path.abspath(os.environ["FVP_LIB"])
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lib  # noqa: E402  (tools/_lib.py: FVP_LIB variant, or the diagnostics build when FVP_* knobs are set)
+_lib.select(_capi0)
 
 
 def per_op(m, x, a):

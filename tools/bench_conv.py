@@ -14,8 +14,9 @@ import torch  # noqa: E402
 import fvp_synthetic as S  # noqa: E402
 from faster_voxelpose_amd import _capi as capi  # noqa: E402
 
-if os.environ.get("FVP_LIB"):          # diagnostics only: a variant built by tools/build_variant.sh
-    capi.LIB_PATH = os.path.abspath(os.environ["FVP_LIB"])
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lib  # noqa: E402  (tools/_lib.py: FVP_LIB variant, or the diagnostics build when FVP_* knobs are set)
+_lib.select(capi)
 from faster_voxelpose_amd.engine import _ptr  # noqa: E402
 from faster_voxelpose_amd.models import faster_voxelpose as FV  # noqa: E402
 

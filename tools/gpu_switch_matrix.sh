@@ -1,7 +1,9 @@
 #!/usr/bin/env bash
 # GPU parity suite under the kernel-selection switches (every alternative form must pass the same tests)
 root="${GRAFT_REPO_ROOT:-$(pwd)}"; cd "$root"; export TMPDIR=/tmp
-run() { echo -n "$* : "; env "$@" timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -x 2>&1 | tail -1; }
+[[ -f tests/diag/libfvp_hip_diag.so ]] || tests/diag/build_diag.sh >/dev/null
+# FVP_TEST_DIAG_LIB=1: tests/conftest.py points the package at the diagnostics build (the shipped library ignores FVP_* switches)
+run() { echo -n "$* : "; env FVP_TEST_DIAG_LIB=1 "$@" timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -x 2>&1 | tail -1; }
 run X=1
 run FVP_TRIPLANE_QUAD=1
 run FVP_TRIPLANE_LANE=1 FVP_TRI_TWO_TILE=1

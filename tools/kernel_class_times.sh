@@ -5,7 +5,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 import fvp_synthetic as S
 from faster_voxelpose_amd import _capi as capi
-if os.environ.get("FVP_LIB"): capi.LIB_PATH = os.path.abspath(os.environ["FVP_LIB"])
+sys.path.insert(0, os.path.join(os.getcwd(), "tools")); import _lib; _lib.select(capi)
 from faster_voxelpose_amd.models import faster_voxelpose as FV
 dev="cuda:0"
 CFGN = os.environ.get("CFG", "panoptic")
