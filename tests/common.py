@@ -46,8 +46,8 @@ def floor_rule_check(case, xyz, g, report=None):
     d32 = np.linalg.norm(f3 - g["fused_poses"][..., :3], axis=-1)            # [B,N,J]
     d64 = np.linalg.norm(f3 - g["floor_fused"], axis=-1)
     pfl = np.linalg.norm(g["fused_poses"][..., :3].astype(np.float64) - g["floor_fused"], axis=-1).max(axis=-1)   # [B,N]
-    r64 = (d64.max(axis=-1) / pfl)[v]
-    r32 = (d32.max(axis=-1) / pfl)[v]
+    r64 = d64.max(axis=-1)[v] / pfl[v]
+    r32 = d32.max(axis=-1)[v] / pfl[v]
     if report is not None:
         report.update(worst_ratio_vs_fp64=float(r64.max()), worst_ratio_vs_ref32=float(r32.max()),
                       proposal_floor_min_mm=float(pfl[v].min()), proposal_floor_max_mm=float(pfl[v].max()))
