@@ -66,6 +66,16 @@
 #ifndef FVP_WINO_IN_AUX
 #define FVP_WINO_IN_AUX 0
 #endif
+// Skewed chunk barrier (round 4): the second wave of every SIMD (waves NWV/2 .. NWV-1 of an 8-wave workgroup) takes the
+// chunk barrier ONE MFMA BURST EARLIER in its instruction stream - in front of the last step's first burst instead of its
+// second.  With the barrier at the same place for everybody the two waves of a SIMD leave it in lock-step: both issue a
+// burst (serialised on the one matrix pipe), then both run their patch transform while the pipe idles, every chunk.
+// Skewed, the late half arrives while the early half still owes one burst, so after the release one wave's vector work
+// always lies beside the other's MFMAs.  Safe because a wave's reads of the slot are complete at either place: the last
+// step's A(cout block 1) is requested at the top of half-step 0 and awaited (lgkmcnt(0)) before the early barrier.
+#ifndef FVP_WINO_SKEW
+#define FVP_WINO_SKEW 1
+#endif
 
 namespace fvp {
 
@@ -408,6 +418,22 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   fetch_a(0, wchunk(smem + 4, 0), 0);
   fetch_d(smem + 4, 0, WP);
   while (true) {
+  // counted wait + barrier of a chunk (see the ring description above); first = the unit's first chunk
+  auto chunk_barrier = [&](auto firstc, bool more) {
+    constexpr bool kFirstB = decltype(firstc)::value;
+    if (dma) {
+      if constexpr (kFirstB || !FVP_WINO_ZERO_C) {
+        // a unit's first chunk: behind an epilogue that drained the DMA queue (st_pending, see there) the chunk this
+        // barrier guards has already landed and the epilogue's stores may stay in flight: no vmcnt wait at all
+        if (!st_pending) wait_vmcnt_small(more ? nps : 0);
+        st_pending = 0;
+      } else {
+        wait_vmcnt_small(more ? nps : 0);          // nps <= 8: a handful of scalar instructions instead of ~30
+      }
+    }
+    if (!(FVP_WINO_DIAG && (a.ablate & 128))) FVP_WINO_BARRIER();     // (bit 128, diagnostics: no chunk barrier)
+  };
+  const bool early = FVP_WINO_SKEW && NWV == 8 && wave >= NWV / 2;   // wave-uniform: this wave takes the barrier one burst early
   // the chunk body exists twice: the unit's first chunk (its first step's MFMAs take C = 0) and every other one
   auto chunk = [&](int k, auto firstc) {
     constexpr bool kFirst = decltype(firstc)::value;
@@ -467,6 +493,14 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       FVP_TS(tC);
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      if (FVP_WINO_SKEW && s + 1 == S && early) {
+        // early barrier of the SIMD's second wave: every read of the slot (this step's patch, A of both cout blocks) has
+        // been requested; wait for them, then the slot is no longer needed by this wave
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        chunk_barrier(std::integral_constant<bool, kFirst>{}, more);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       mfma16(0, kFirst && s == 0);
       __builtin_amdgcn_sched_barrier(0);
       FVP_TS(tD);
@@ -479,30 +513,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       } else {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
         // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
-        if (dma) {
-          if constexpr (kFirst || !FVP_WINO_ZERO_C) {
-            // a unit's first chunk: behind an epilogue that drained the DMA queue (st_pending, see there) the chunk this
-            // barrier guards has already landed and the epilogue's stores may stay in flight: no vmcnt wait at all
-            if (!st_pending) wait_vmcnt_small(more ? nps : 0);
-            st_pending = 0;
-          } else {
-            wait_vmcnt_small(more ? nps : 0);          // nps <= 8: a handful of scalar instructions instead of ~30
-          }
-        }
-#if FVP_WINO_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        tV = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (!(FVP_WINO_DIAG && (a.ablate & 128))) FVP_WINO_BARRIER();     // (bit 128, diagnostics: no chunk barrier)
-#if FVP_WINO_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        tBar = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_sched_barrier(0);
-        tacc[8] += tV - tEE; tacc[9] += tBar - tV;
-#endif
+        if (!early) chunk_barrier(std::integral_constant<bool, kFirst>{}, more);
         if (k + 1 < nchunks) {                       // (a unit's last chunk: the epilogue needs the registers)
           fetch_a(0, wchunk(nxt, k + 1), 0);
           fetch_d(nxt, 0, wp);
