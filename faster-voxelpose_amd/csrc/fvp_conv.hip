@@ -901,7 +901,6 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
 
 }  // namespace fvp
 #include "fvp_conv_wino.h"
-#include "fvp_conv_wino1w.h"
 namespace fvp {
 
 // max_pool(2,2) / max_pool1d(2): one thread per output element.
@@ -1104,15 +1103,6 @@ static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, 
   return res ? launch_wino2<WC, WT, 4, true>(a, grid, lds, s) : launch_wino2<WC, WT, 4, false>(a, grid, lds, s);
 }
 
-template <int CC, bool RES>
-static int launch_wino1w(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static LdsOptIn optin;
-  auto k = &k_conv_wino1w<CC, RES>;
-  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), 160 * 1024)) return e;
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
-  return launch_status();
-}
-
 // one persistent 8-wave workgroup per CU
 static int persistent_workgroups() {
   static int n = 0;
@@ -1156,15 +1146,9 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   const size_t budget = WC * WT == 4 ? std::min<size_t>(kWinoLdsBudget, 78 * 1024) : kWinoLdsBudget;   // two workgroups per CU
   const size_t epi_bytes = size_t(3) * op.coutp * 4;     // bias | scale | shift in LDS
   bool resw = WC == 1 && WT == 8 && op.coutp == 32 && op.cinp % 8 == 0 && resw_bytes <= 64 * 1024 && !kWinoNoResW;
-  // 64 couts x 64 tiles per workgroup and cout % 64 == 0: the one-wave-per-SIMD kernel (fvp_conv_wino1w.h): the same
-  // workgroup tile, LDS layout and arithmetic done by 4 waves with 256 accumulator registers each.  A SHAPE rule.
-  // Measured 35 % SLOWER than the two-wave kernel (64->64 @32x32: 146 vs 107 us, 128->128 @16x16: 125 vs 94 us): a lone
-  // wave has nobody to cover its LDS-DMA issue stalls (12 per chunk) and barrier waits.  Kept out of the product path;
-  // FVP_WINO_1W=1 (diagnostics build only, read per call) selects it for the bit-identity test and for measurements.
-  const bool one_wave = WC == 2 && WT == 4 && fvp::diag_env("FVP_WINO_1W") != nullptr;
   auto slot_bytes = [&](int cc, int* ni, bool rw) {
     const size_t quads = size_t(cc) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1;
-    const size_t per_round = one_wave ? 256 : size_t(WC) * WT * 64;   // one 16-byte item per thread and round
+    const size_t per_round = size_t(WC) * WT * 64;       // one 16-byte item per thread and round
     *ni = int((quads + per_round - 1) / per_round);
     return size_t(*ni) * per_round * 16 + (rw ? 0 : size_t(cc) * CBW * 64);
   };
@@ -1215,11 +1199,6 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
   }
   return rc;
 #else
-  if (one_wave) {
-    const bool res = a.flags & FVP_EPI_RES;
-    if (a.CC == 8) return res ? launch_wino1w<8, true>(a, grid, lds, s) : launch_wino1w<8, false>(a, grid, lds, s);
-    return res ? launch_wino1w<4, true>(a, grid, lds, s) : launch_wino1w<4, false>(a, grid, lds, s);
-  }
   if (WC * WT == 4) return launch_wino<1, 4>(a, grid, lds, s, false);
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false);
 #endif

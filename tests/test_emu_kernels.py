@@ -283,18 +283,3 @@ def test_fused_projection_one_tile_two_tile_and_gather_rectangles(emu_lib, monke
         got = model.engine.last_jln["planes"].clone()
     assert want.abs().sum() > 0 and torch.equal(got, want)
 
-
-@pytest.mark.parametrize("cin,cout,hw,planes", [(64, 64, (16, 16), 7), (32, 128, (8, 8), 13), (128, 128, (16, 16), 3)])
-def test_one_wave_per_simd_winograd_equals_two_wave_kernel(emu_lib, monkeypatch, cin, cout, hw, planes):
-    """k_conv_wino1w (one wave per SIMD, 64 couts x 16 tiles per wave, round 4) against float64 torch and, bit for bit,
-    against k_conv_wino on the same layer (FVP_WINO_NO_1W=1 in the diagnostics build): the kernels perform the same
-    arithmetic in the same order, so the choice cannot change a result.  Ragged plane counts (partial last plane group),
-    conv + residual + ReLU, several units per persistent workgroup (the emulated device has 3 CUs)."""
-    spec, w, ref, o = split_k_stack(cin, cout, hw, seed=cout)
-    assert any(op.wino_off > 0 for op in spec.op_array)
-    x = torch.from_numpy(np.random.default_rng(7).normal(size=(planes, cin) + hw).astype(np.float32))
-    old = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)[o]
-    monkeypatch.setenv("FVP_WINO_1W", "1")
-    new = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)[o]
-    np.testing.assert_allclose(new.double().numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5)
-    assert torch.equal(new, old)
