@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Pipelined throughput of the voxel path (B frames per batch, D batches in flight) for A/B runs of library variants
+(FVP_LIB=<variant .so>, or FVP_* knobs -> the diagnostics build; tools/_lib.py).  Diagnostics only: the judged number
+comes from bench.py with the product library."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+
+import fvp_synthetic as S  # noqa: E402
+from faster_voxelpose_amd import _capi as capi  # noqa: E402
+import _lib  # noqa: E402
+
+_lib.select(capi)
+from faster_voxelpose_amd.models import faster_voxelpose as FV  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="panoptic")
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--streams", type=int, default=3)
+ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+dev = "cuda:0"
+cfg = S.make_cfg(a.config, device=dev, min_score=-1.0)
+cams, seq = S.load_cameras(a.config)
+rt = S.resize_transform(cfg).to(dev)
+heats = [S.heatmaps_blobs(cfg, cams, seq, a.batch, people=4, seed=100 + i).to(dev) for i in range(4)]
+meta = {"seq": [seq] * a.batch}
+model = FV.get(cfg).to(dev)
+model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
+pipe = FV.PipelinedForward(model, depth=a.streams)
+with torch.no_grad():
+    for i in range(6):
+        pipe.submit(meta=meta, input_heatmaps=heats[i % 4], cameras=cams, resize_transform=rt)
+    pipe.synchronize()
+    rates = []
+    for r in range(a.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            pipe.submit(meta=meta, input_heatmaps=heats[i % 4], cameras=cams, resize_transform=rt)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        rates.append(a.steps * a.batch / (time.perf_counter() - t0))
+print(f"{os.path.basename(capi.LIB_PATH)}: {a.config} B={a.batch} x{a.streams}: frames/s " + " ".join(f"{x:.0f}" for x in rates))
