@@ -20,6 +20,22 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class SharedGeometry:
+    """Per-sequence camera tables and the fine-grid coordinate cache of one device.  Read-only between (re)builds, so
+    every replica of a ``PipelinedForward`` (one per batch in flight, each on its own HIP stream) uses ONE copy - each
+    replica used to build and re-read its own 164 MB cache (Panoptic).  ``ready`` is the completion event of the last
+    (re)build on the stream that issued it: users on other streams wait for it; superseded tensors are kept alive
+    (``retired``) because launches queued on other streams may still read them."""
+
+    def __init__(self):
+        self.cams = None          # [nsets, V, 24]
+        self.seq_ids = {}
+        self.fine_grid = None     # [nsets, V, F0*F1*F2, 2]
+        self.fine_grid_key = None
+        self.ready = None
+        self.retired = []
+
+
 class HotPath:
     def __init__(self, cfg, _lib=None):
         # `_lib` is a test seam (tests/hipemu); the product always loads libfvp_hip.so
@@ -74,8 +90,7 @@ class HotPath:
         self.cache_fine_grid = not self._injected     # (the CPU emulation of the kernels builds it too slowly for every test)
         self.fine_grid_limit_bytes = 2 << 30           # per camera set
         self.fine_grid_total_limit_bytes = 8 << 30     # all sets of this replica together (288 GB of HBM per GPU)
-        self._fine_grid = None
-        self._fine_grid_key = None
+        self.geo = SharedGeometry()                    # cameras + coordinate cache (shared by pipeline replicas)
         self.fine_axes = axes(cs.SPACE_SIZE, cs.SPACE_CENTER, self.fine)
         # center_grid [3, C*C, 2] (project_individual.py:37-40): xy at z0, xz at y0, yz at x0
         ia = axes(ins.SPACE_SIZE, cs.SPACE_CENTER, ins.VOXELS_PER_AXIS)
@@ -96,8 +111,6 @@ class HotPath:
         self.wn_params = torch.zeros(self.F * 12 + self.Hd * self.F + 2 * self.Hd + 4, device=dev)
         self._geom = None
         self._geom_key = None
-        self._cams = None
-        self._seq_ids = {}
         self._frame_sets = {}
         self._heat_key = None
         self._heat_cl = None
@@ -161,23 +174,44 @@ class HotPath:
 
     def frame_sets(self, meta, cameras, V):
         """Per-frame camera-set ids (one set per sequence), uploading new sequences once."""
+        geo = self.geo
         seqs = tuple(meta["seq"])
-        new = [s for s in dict.fromkeys(seqs) if s not in self._seq_ids]
+        new = [s for s in dict.fromkeys(seqs) if s not in geo.seq_ids]
         for s in new:
             assert s in cameras.keys(), "missing camera parameters for the current sequence"
             assert len(cameras[s]) == V, "inconsistent number of cameras"
             rows = np.stack([self._cam_row(cameras[s][c]) for c in range(V)])
             t = torch.from_numpy(rows).to(self.device)
-            self._cams = t[None] if self._cams is None else torch.cat([self._cams, t[None]], dim=0)
-            self._seq_ids[s] = self._cams.shape[0] - 1
-            self._frame_sets.clear()
+            if geo.cams is not None:
+                geo.retired.append(geo.cams)
+            geo.cams = t[None] if geo.cams is None else torch.cat([geo.cams, t[None]], dim=0)
+            geo.seq_ids[s] = geo.cams.shape[0] - 1      # ids are append-only: other replicas' frame-set tensors stay valid
+        if new:
+            self._geometry_changed()
+        else:
+            self._await_geometry()
         if seqs not in self._frame_sets:
-            self._frame_sets[seqs] = torch.tensor([self._seq_ids[s] for s in seqs], dtype=torch.int32,
+            self._frame_sets[seqs] = torch.tensor([geo.seq_ids[s] for s in seqs], dtype=torch.int32,
                                                   device=self.device)
         return self._frame_sets[seqs]
 
+    def _geometry_changed(self):
+        """Mark the shared tables as (re)built by work queued on the current stream."""
+        if self.device.type == "cuda":
+            self.geo.ready = torch.cuda.Event()
+            self.geo.ready.record(torch.cuda.current_stream(self.device))
+
+    def _await_geometry(self):
+        """Order the current stream behind the last (re)build of the shared tables (a no-op once it has completed)."""
+        ev = self.geo.ready
+        if ev is not None:
+            if ev.query():
+                self.geo.ready = None
+            else:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+
     def cams_of(self, seq):
-        return self._cams[self._seq_ids[seq]]
+        return self.geo.cams[self.geo.seq_ids[seq]]
 
     def fine_grid_cache(self, resize_transform, V):
         """[nsets, V, F0*F1*F2, 2] sampling coordinates of the fine grid for every uploaded camera set (built by
@@ -185,27 +219,36 @@ class HotPath:
         ``fine_grid_limit_bytes`` or all sets together ``fine_grid_total_limit_bytes`` (the kernel then recomputes
         the projection: same bits).  The cache belongs to one (resize_transform, V): it is rebuilt when
         ``geom()`` re-derives the geometry, never silently reused."""
+        geo = self.geo
         n = self.fine[0] * self.fine[1] * self.fine[2]
-        nsets = self._cams.shape[0]
+        nsets = geo.cams.shape[0]
         if V * n * 8 > self.fine_grid_limit_bytes or nsets * V * n * 8 > self.fine_grid_total_limit_bytes:
-            self._fine_grid = None
+            if geo.fine_grid is not None:
+                geo.retired.append(geo.fine_grid)
+            geo.fine_grid = None
             return None
         g = self.geom(resize_transform)
         key = (tuple(g.rt), g.clamp_max, V)
-        if self._fine_grid is not None and self._fine_grid_key != key:
-            self._fine_grid = None                      # resize_transform changed: stale coordinates
-        have = 0 if self._fine_grid is None else self._fine_grid.shape[0]
+        if geo.fine_grid is not None and geo.fine_grid_key != key:
+            geo.retired.append(geo.fine_grid)
+            geo.fine_grid = None                        # resize_transform changed: stale coordinates
+        have = 0 if geo.fine_grid is None else geo.fine_grid.shape[0]
         if have < nsets:
             g.V = V
+            self._await_geometry()                      # (another replica may still be writing the part that is copied)
             new = torch.empty((nsets, V, n, 2), device=self.device)
             if have:
-                new[:have] = self._fine_grid
+                new[:have] = geo.fine_grid
+                geo.retired.append(geo.fine_grid)
             fa = self.fine_axes
             for i in range(have, nsets):
                 self._call("fvp_sample_grid", _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), self.fine[0], self.fine[1],
-                           self.fine[2], _ptr(self._cams[i]), C.byref(g), _ptr(new[i]), self.stream())
-            self._fine_grid, self._fine_grid_key = new, key
-        return self._fine_grid
+                           self.fine[2], _ptr(geo.cams[i]), C.byref(g), _ptr(new[i]), self.stream())
+            geo.fine_grid, geo.fine_grid_key = new, key
+            self._geometry_changed()
+        else:
+            self._await_geometry()
+        return geo.fine_grid
 
     # ---- staging ---------------------------------------------------------------------------------------
     def heat_cl(self, heatmaps, g, reuse=False):
@@ -301,7 +344,7 @@ class HotPath:
         cubes = torch.empty((B, self.J, self.X, self.Y, self.Z), device=self.device) if want_cubes else None
         zmax = self.scratch("zmax", (B, self.J, self.X, self.Y)) if want_zmax else None
         ax = self.whole_axes
-        self._call("fvp_project_whole", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
+        self._call("fvp_project_whole", _ptr(hcl), _ptr(self.geo.cams), _ptr(fs), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
                    self.X, self.Y, self.Z, B, C.byref(g), _ptr(cubes), _ptr(zmax), self.stream())
         return cubes, zmax
 
@@ -340,7 +383,7 @@ class HotPath:
                        _ptr(match_bbox), None, s)
             g = self.geom(resize_transform)
             ax = self.whole_axes
-            self._call("fvp_project_columns", _ptr(self._heat_cl), _ptr(self._cams),
+            self._call("fvp_project_columns", _ptr(self._heat_cl), _ptr(self.geo.cams),
                        _ptr(self.frame_sets(meta, cameras, heatmaps.shape[1])), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
                        X, Y, Z, B, C.byref(g), _ptr(flat), N, _ptr(feat1d), s)
         if self.fused_c2c and Z <= 24:
@@ -421,12 +464,12 @@ class HotPath:
         planes = self.scratch("planes", (nP, 3, J, Cn, Cn), zero=True)
         if fused:
             fgrid = self.fine_grid_cache(resize_transform, V) if self.cache_fine_grid else None
-            self._call("fvp_project_individual_triplane", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),
+            self._call("fvp_project_individual_triplane", _ptr(hcl), _ptr(self.geo.cams), _ptr(fs), _ptr(pf), _ptr(valid),
                        _ptr(boxes), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), self.fine_host, Cn, nP, C.byref(g),
                        _ptr(planes), N, _ptr(fgrid), s)
         else:
             cubes = self.scratch("person_cubes", (nP, J, Cn, Cn, Cn))
-            self._call("fvp_project_individual", _ptr(hcl), _ptr(self._cams), _ptr(fs), _ptr(pf), _ptr(valid),
+            self._call("fvp_project_individual", _ptr(hcl), _ptr(self.geo.cams), _ptr(fs), _ptr(pf), _ptr(valid),
                        _ptr(boxes), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), _ptr(self.fine_dev), Cn, nP, C.byref(g),
                        _ptr(cubes), s)
             self._call("fvp_triplane_max", _ptr(cubes), _ptr(planes), nP, J, Cn, s)

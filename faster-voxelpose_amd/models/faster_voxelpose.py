@@ -105,6 +105,9 @@ class PipelinedForward:
             m = FasterVoxelPoseNet(model.cfg).to(model.device)
             m.load_state_dict(model.state_dict())
             m.eval()
+            # camera tables and the per-sequence coordinate cache (164 MB for the Panoptic shape set) are read-only
+            # between rebuilds: one copy for all replicas (engine.SharedGeometry orders the streams behind a rebuild)
+            m.engine.geo = model.engine.geo
             self.models.append(m)
         self.depth = depth
         self._i = 0

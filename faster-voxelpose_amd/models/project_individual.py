@@ -55,7 +55,7 @@ class ProjectLayer(nn.Module):
         s = e.stream()
         e._call("fvp_person_boxes", _ptr(centers), P, _ptr(e.ind_consts), e.fine_cube, _ptr(boxes), _ptr(offset), s)
         fa = e.fine_axes
-        e._call("fvp_project_individual", _ptr(hcl), _ptr(e._cams), _ptr(fs), _ptr(pf), None, _ptr(boxes), _ptr(fa[0]),
+        e._call("fvp_project_individual", _ptr(hcl), _ptr(e.geo.cams), _ptr(fs), _ptr(pf), None, _ptr(boxes), _ptr(fa[0]),
                 _ptr(fa[1]), _ptr(fa[2]), _ptr(e.fine_dev), e.C, P, C.byref(g), _ptr(cubes), s)
         self.last_boxes = boxes
         return cubes, offset

@@ -209,7 +209,7 @@ def test_cached_fine_grid_gives_identical_planes(emu_lib):
         planes1 = model.engine.last_jln["planes"].clone()
         model.engine.cache_fine_grid = True
         f2, p2, c2, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
-    assert model.engine._fine_grid is not None
+    assert model.engine.geo.fine_grid is not None
     assert torch.equal(model.engine.last_jln["planes"], planes1) and torch.equal(f1, f2) and torch.equal(p1, p2)
 
 

@@ -25,7 +25,7 @@ with torch.no_grad():
     model(meta={"seq": [seq] * B}, input_heatmaps=heat, cameras=cams, resize_transform=rt)
 e = model.engine
 boxes = e.last_jln["boxes"].cpu().numpy()                      # [nP, 9]
-grid = e._fine_grid[0]                                         # [V, F0*F1*F2, 2]
+grid = e.geo.fine_grid[0]                                         # [V, F0*F1*F2, 2]
 F0, F1, F2 = e.fine
 V = grid.shape[0]
 W, H = e.W, e.H
