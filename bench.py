@@ -237,8 +237,22 @@ def mpjpe_vs_reference(dev):
     except Exception as e:                                   # fixtures absent: the two cases above still stand
         out["seed_sweep"] = {"error": repr(e)}
     first = out["panoptic_c_b2_thr"]
+    # one line per shape: the conditioned fixture where there is one, the well-conditioned proposals of the seed sweep
+    # (rule R1p of tests/golden/seed_sweep.py) for jln128
+    def sw(name):
+        e = out.get("sweep_" + name) or {}
+        return {"joints": e.get("joints_of_proposals_with_floor_le_4e-4"), "max": e.get("max_mm_in_proposals_with_floor_le_4e-4"),
+                "frac_of_all_joints_within_1e-3": e.get("frac_within_1e-3_mm")}
+    by_shape = {"panoptic (jln64)": {"max": first["max"], "mean": first["mean"], "bar": 1e-3},
+                "shelf": {"max": out["shelf_c_b1_thr"]["max"], "mean": out["shelf_c_b1_thr"]["mean"], "bar": 1e-3},
+                "campus": {"max": out["campus_c_b2_thr"]["max"], "reference_own_fp32_vs_fp64_max": out["campus_c_b2_thr"]["reference_fp32_vs_fp64_floor_max"],
+                           "build_vs_fp64_over_reference_vs_fp64": out["campus_c_b2_thr"].get("worst_build_vs_fp64_over_reference_vs_fp64"),
+                           "bar": "ratio <= 1.5 (FLOOR_RULE)"},
+                "panoptic128 (jln128, 10-seed sweep, well-conditioned proposals)": dict(sw("panoptic128_b1"), bar=1e-3),
+                "panoptic B = 8 (10-seed sweep, well-conditioned proposals)": dict(sw("panoptic_b8"), bar=1e-3)}
     return {"fixture": "panoptic_c_b2_thr (Panoptic 5-view 80x80x20 jln64, 8 valid people; reference outputs committed "
-                       "under tests/golden)", "mean": first["mean"], "max": first["max"], "bar": 1e-3, "all": out}
+                       "under tests/golden)", "mean": first["mean"], "max": first["max"], "bar": 1e-3,
+            "by_shape": by_shape, "all": out}
 
 
 # ---- the workload -----------------------------------------------------------------------------------------------
