@@ -283,3 +283,34 @@ def test_fused_projection_one_tile_two_tile_and_gather_rectangles(emu_lib, monke
         got = model.engine.last_jln["planes"].clone()
     assert want.abs().sum() > 0 and torch.equal(got, want)
 
+
+
+@pytest.mark.parametrize("J,V", [(1, 3), (32, 3), (21, 3), (5, 1), (5, 8)])
+def test_joint_and_view_count_extremes(emu_lib, J, V):
+    """The limits include/fvp.h states (FVP_MAX_JOINTS = 32, FVP_MAX_VIEWS = 8) and the minima (one joint, one view; J = 21
+    -> JP = 24, a channel padding none of the shipped configs has): the whole forward on the miniature shape against the
+    oracle - proposal centres / valid flags exact, joints inside the random-weight noise floor."""
+    import copy
+    cfg = S.make_cfg("tiny", device="cpu", min_score=-1.0)
+    cfg.DATASET.NUM_JOINTS, cfg.DATASET.CAMERA_NUM = J, V
+    cams0, seq = S.load_cameras("tiny")
+    base = cams0[seq]
+    cl = []
+    for i in range(V):                                  # cameras beyond the three of the fixture: shifted copies
+        c = copy.deepcopy(base[i % len(base)])
+        c["T"] = (np.asarray(c["T"], np.float64).reshape(3, 1) + np.array([[37.0 * i], [-21.0 * i], [5.0 * i]])).tolist()
+        cl.append(c)
+    cams = {seq: cl}
+    rt = S.resize_transform(cfg)
+    heat = S.heatmaps_uniform(cfg, 2, seed=4)
+    model = FV.FasterVoxelPoseNet(cfg, _lib=emu_lib)
+    sd = S.fill_state_dict(model.state_dict(), seed=3)
+    model.load_state_dict(sd)
+    meta = {"seq": [seq] * 2}
+    with torch.no_grad():
+        fused, planes, centers, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+    of, op, oc = O.Oracle(cfg, sd).forward(heat, meta, cams, rt)
+    assert fused.shape == (2, cfg.CAPTURE_SPEC.MAX_PEOPLE, J, 5) and planes.shape == (3, 2, cfg.CAPTURE_SPEC.MAX_PEOPLE, J, 2)
+    assert torch.equal(centers[..., :4], oc[..., :4])
+    np.testing.assert_allclose(fused[..., :3].numpy(), of[..., :3].numpy(), rtol=0, atol=2e-2)     # mm
+    np.testing.assert_allclose(fused[..., 4].numpy(), of[..., 4].numpy(), rtol=2e-4, atol=1e-6)
