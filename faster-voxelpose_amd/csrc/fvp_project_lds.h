@@ -449,6 +449,208 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Round 4: the quad form WITHOUT LDS staging.  Measured in round 3: with every rectangle forced onto the global-gather
+// path the staged quad kernel takes 493 us against 490 - its sampling is bound by the instruction stream, and the compact
+// 8 x 4 x 32 voxel block (not the LDS tile) is what made it faster than the round-1 gather kernel: neighbouring voxels'
+// taps hit the CU's L1 / the XCD's L2.  So the staging machinery - rectangle reductions (DPP + LDS atomics), the tile DMA,
+// one workgroup barrier per view, two 36 KB tiles - buys the JP = 16 form nothing and costs the "skeleton" time.  This
+// kernel keeps the block shape, the lane mapping, the coordinate cache and the plane-maxima phase, and samples every tap
+// with global_load_dwordx4 (address-space-qualified: no FLAT): no barrier inside the view loop, waves run free, LDS only
+// for the block's plane cells.  Same arithmetic per sample in the same order: bit-equal planes.
+#ifndef FVP_TRI_BLK_OCC
+#define FVP_TRI_BLK_OCC 4
+#endif
+template <int NVL, bool CACHED>
+__global__ void __launch_bounds__(kTriThreads, FVP_TRI_BLK_OCC)
+k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
+                       const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
+                       const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
+                       const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, FvpGeom g,
+                       const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes) {
+  constexpr int BZ = NVL == 1 ? 32 : 16;
+  constexpr int VPT = BZ / 4;
+  constexpr int OWN = VPT / 4;
+  HIP_DYNAMIC_SHARED(float, smem)                     // the block's plane cells (ints)
+  constexpr int NT = kTriThreads;
+  const int J = g.J, JP = g.JP, CC = C * C, V = g.V, W = g.W, H = g.H;
+  int p, blk;
+  {
+    const int id = blockIdx.x;
+    const int bpp = nbx * nby, bpf = ppf * bpp;
+    const int nframes = nP / ppf;
+    if (nframes % 8 == 0) {
+      const int xcd = id & 7, j = id >> 3;
+      const int frame = xcd + 8 * (j / bpf), r = j % bpf;
+      p = frame * ppf + r / bpp;
+      blk = r % bpp;
+    } else {
+      p = id / bpp;
+      blk = id % bpp;
+    }
+  }
+  if (person_valid && !person_valid[p]) return;
+  const int* bx = boxes + p * 9;
+  const int tl0 = bx[0], tl1 = bx[1], tl2 = bx[2];
+  const int s0 = bx[3], s1 = bx[4], s2 = bx[5], e0 = bx[6], e1 = bx[7], e2 = bx[8];
+  if (s0 >= e0 || s1 >= e1 || s2 >= e2) return;
+  const int xb = blk / nby, yb = blk - xb * nby;
+  const int gx0 = s0 + xb * kBX, gy0 = s1 + yb * kBY;
+  if (gx0 >= e0 || gy0 >= e1) return;
+
+  const int t = threadIdx.x, q = t & 3;
+  const int slot = t >> 2, zs = slot & 3, yy = (slot >> 2) & (kBY - 1), xx = slot / (4 * kBY);
+  const int gxi = gx0 + xx, gyi = gy0 + yy;
+  const bool col_in = gxi < e0 && gyi < e1;
+  const int b = person_frame[p];
+  const size_t view_stride = size_t(H) * W * JP;
+  const float* frame = heat_cl + size_t(b) * V * view_stride;
+  const Cam* cm = cams + size_t(frame_set[b]) * V;
+  const float wx = col_in ? fx[gxi] : 0.0f, wy = col_in ? fy[gyi] : 0.0f;
+  const size_t nfine = size_t(F0) * F1 * F2;
+  const float2* gcol = CACHED ? reinterpret_cast<const float2*>(fgrid) + size_t(frame_set[b]) * V * nfine +
+                                    (size_t(col_in ? gxi : 0) * F1 + (col_in ? gyi : 0)) * F2
+                              : nullptr;
+  float* pxy = planes + (size_t(p) * 3 + 0) * J * CC;
+  float* pxz = planes + (size_t(p) * 3 + 1) * J * CC;
+  float* pyz = planes + (size_t(p) * 3 + 2) * J * CC;
+  const float nv = float(V);
+
+  for (int gz0 = s2; gz0 < e2; gz0 += BZ) {
+    float acc[VPT][NVL][4];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+      for (int n = 0; n < NVL; ++n)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][n][c] = 0.0f;
+    float2 crd[OWN];
+    auto load_coords = [&](int v) {
+#pragma unroll
+      for (int k = 0; k < OWN; ++k) {
+        const int gzi = gz0 + zs + 4 * (q + 4 * k);
+        crd[k] = gcol[size_t(v) * nfine + (gzi < F2 ? gzi : F2 - 1)];
+      }
+    };
+    if (CACHED) load_coords(0);
+    for (int v = 0; v < V; ++v) {
+      // this lane's own voxels (i = q + 4 k) of view v: tap descriptor relative to the view's plane
+      TapL mine[OWN];
+#pragma unroll
+      for (int k = 0; k < OWN; ++k) {
+        const int gzi = gz0 + zs + 4 * (q + 4 * k);
+        const bool vin = col_in && gzi < e2;
+        TapL d;
+        d.base = d.dx = d.dy = 0;
+        d.w[0] = d.w[1] = d.w[2] = d.w[3] = 0.0f;
+        if (vin) {
+          float sx, sy;
+          if (CACHED) {
+            sx = crd[k].x;
+            sy = crd[k].y;
+          } else {
+            project_norm(cm[v], g, wx, wy, fz[gzi], sx, sy);
+          }
+          int x0, y0, inside;
+          float w4[4];
+          tap_origin(sx, sy, W, H, x0, y0, w4, inside);
+          const int cx0 = imin(imax(x0, 0), W - 1), cx1 = imin(imax(x0 + 1, 0), W - 1);
+          const int cy0 = imin(imax(y0, 0), H - 1), cy1 = imin(imax(y0 + 1, 0), H - 1);
+          d.base = (cy0 * W + cx0) * JP;
+          d.dx = (cx1 - cx0) * JP;
+          d.dy = (cy1 - cy0) * W * JP;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d.w[c] = ((inside >> c) & 1) ? w4[c] : 0.0f;
+        }
+        mine[k] = d;
+      }
+      if (CACHED && v + 1 < V) load_coords(v + 1);     // next view's coordinates under this view's sampling
+      const float* gsrc = frame + size_t(v) * view_stride;
+      auto sample = [&](const TapL& tv, float (&a)[NVL][4]) {
+#pragma unroll
+        for (int n = 0; n < NVL; ++n) {
+          const int ch0 = 16 * n + 4 * q;
+          if (ch0 < JP) {
+            const float* p0 = gsrc + tv.base + ch0;
+            const float4 v0 = glb_ld4(p0), v1 = glb_ld4(p0 + tv.dx), v2 = glb_ld4(p0 + tv.dy), v3 = glb_ld4(p0 + tv.dy + tv.dx);
+            const f32x2 w0 = f32x2{tv.w[0], tv.w[0]}, w1 = f32x2{tv.w[1], tv.w[1]}, w2 = f32x2{tv.w[2], tv.w[2]},
+                        w3 = f32x2{tv.w[3], tv.w[3]};
+            f32x2 lo = f32x2{v0.x, v0.y} * w0, hi = f32x2{v0.z, v0.w} * w0;
+            lo = __builtin_elementwise_fma(f32x2{v1.x, v1.y}, w1, lo);
+            hi = __builtin_elementwise_fma(f32x2{v1.z, v1.w}, w1, hi);
+            lo = __builtin_elementwise_fma(f32x2{v2.x, v2.y}, w2, lo);
+            hi = __builtin_elementwise_fma(f32x2{v2.z, v2.w}, w2, hi);
+            lo = __builtin_elementwise_fma(f32x2{v3.x, v3.y}, w3, lo);
+            hi = __builtin_elementwise_fma(f32x2{v3.z, v3.w}, w3, hi);
+            const f32x2 alo = f32x2{a[n][0], a[n][1]} + lo, ahi = f32x2{a[n][2], a[n][3]} + hi;
+            a[n][0] = alo.x; a[n][1] = alo.y; a[n][2] = ahi.x; a[n][3] = ahi.y;
+          }
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < OWN; ++k) {
+        { const TapL tv = quad_bcast_l<0>(mine[k]); sample(tv, acc[4 * k + 0]); }
+        { const TapL tv = quad_bcast_l<1>(mine[k]); sample(tv, acc[4 * k + 1]); }
+        { const TapL tv = quad_bcast_l<2>(mine[k]); sample(tv, acc[4 * k + 2]); }
+        { const TapL tv = quad_bcast_l<3>(mine[k]); sample(tv, acc[4 * k + 3]); }
+      }
+    }
+    // ---- block maxima through LDS, then into the global planes (as k_project_triplane_lds)
+    int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JP]
+    int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][BZ][JP]
+    int* cyz = cxz + kBX * BZ * JP;                                      // [kBY][BZ][JP]
+    const int ncell = (kBX * kBY + (kBX + kBY) * BZ) * JP;
+    __syncthreads();                                                     // (the previous z block's readers are done)
+    for (int i = t; i < ncell; i += NT) cxy[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NVL; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ch = 16 * n + 4 * q + c;
+        float mz = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+          const float val = fmaxf(acc[i][n][c], 0.0f);
+          mz = fmaxf(mz, val);
+          if (val > 0.0f && ch < JP) {
+            const int z = zs + 4 * i;
+            atomicMax(&cxz[(xx * BZ + z) * JP + ch], __float_as_int(val));
+            atomicMax(&cyz[(yy * BZ + z) * JP + ch], __float_as_int(val));
+          }
+        }
+        int mi = __float_as_int(mz);
+        mi = imax(mi, dpp_i<0x124>(mi));
+        mi = imax(mi, dpp_i<0x128>(mi));
+        if (zs == 0 && mi > 0 && ch < JP) cxy[(xx * kBY + yy) * JP + ch] = mi;
+      }
+    __syncthreads();
+    const int lz0 = gz0 - tl2;
+    for (int i = t; i < kBX * kBY * J; i += NT) {
+      const int ch = i / (kBX * kBY), col = i - ch * (kBX * kBY), cx = col / kBY, cy = col - cx * kBY;
+      const int raw = cxy[col * JP + ch];
+      if (raw > 0 && gx0 + cx < e0 && gy0 + cy < e1) {
+        const int vv = __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f));
+        if (vv > 0) plane_max(&pxy[size_t(ch) * CC + (gx0 + cx - tl0) * C + (gy0 + cy - tl1)], vv);
+      }
+    }
+    for (int i = t; i < (kBX + kBY) * BZ * J; i += NT) {
+      const int ch = i / ((kBX + kBY) * BZ), r = i - ch * ((kBX + kBY) * BZ), a = r / BZ, z = r - a * BZ;
+      if (gz0 + z < e2) {
+        const int raw = cxz[r * JP + ch];
+        const int vv = raw > 0 ? __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f)) : 0;
+        if (vv > 0) {
+          if (a < kBX) {
+            if (gx0 + a < e0) plane_max(&pxz[size_t(ch) * CC + (gx0 + a - tl0) * C + lz0 + z], vv);
+          } else if (gy0 + a - kBX < e1) {
+            plane_max(&pyz[size_t(ch) * CC + (gy0 + a - kBX - tl1) * C + lz0 + z], vv);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Round 3: the same kernel with ONE LANE PER VOXEL (all JP channels) instead of four lanes per voxel (a channel quad
 // each).  Ablations of the quad form (80 people, FVP_TRI_ABLATE): 494 us complete = 225 us sampling + 104 us
 // plane maxima + ~175 us skeleton (projection, rectangles, barriers); the tile DMA is hidden (15 us).  The sampling is

@@ -285,7 +285,7 @@ def test_fused_projection_one_tile_two_tile_and_gather_rectangles(emu_lib, monke
 
 
 
-@pytest.mark.parametrize("J,V", [(1, 3), (32, 3), (21, 3), (5, 1), (5, 8)])
+@pytest.mark.parametrize("J,V", [(1, 3), (32, 3), (21, 3), (15, 3), (5, 1), (5, 8)])
 def test_joint_and_view_count_extremes(emu_lib, J, V):
     """The limits include/fvp.h states (FVP_MAX_JOINTS = 32, FVP_MAX_VIEWS = 8) and the minima (one joint, one view; J = 21
     -> JP = 24, a channel padding none of the shipped configs has): the whole forward on the miniature shape against the
@@ -314,3 +314,10 @@ def test_joint_and_view_count_extremes(emu_lib, J, V):
     assert torch.equal(centers[..., :4], oc[..., :4])
     np.testing.assert_allclose(fused[..., :3].numpy(), of[..., :3].numpy(), rtol=0, atol=2e-2)     # mm
     np.testing.assert_allclose(fused[..., 4].numpy(), of[..., 4].numpy(), rtol=2e-4, atol=1e-6)
+    # the fused projection (J = 15 -> JP = 16: the unstaged compact-block form the Panoptic shape takes) against the
+    # materialised cubes + tri-plane maxima: bit for bit
+    planes_fused = model.engine.last_jln["planes"].clone()
+    model.joint_net.fused_projection = False
+    with torch.no_grad():
+        model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+    assert torch.equal(model.engine.last_jln["planes"], planes_fused)
