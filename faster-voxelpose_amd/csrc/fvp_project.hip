@@ -853,15 +853,16 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   // JP = 16 (Panoptic): the compact-block form WITHOUT LDS staging (k_project_triplane_blk, round 4).  FVP_TRIPLANE_STAGED=1
   // (diagnostics build) keeps the staged quad form for comparison; both give the same bits.
   if (!gather && nvl == 1 && !quad_form && !fvp::diag_env("FVP_TRIPLANE_STAGED")) {
-    const size_t lds_b = size_t(kBX * kBY + (kBX + kBY) * 32) * g->JP * 4;
+    const int nbx2 = ceil_div(C, kBlkBX);
+    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * kBlkBZ) * g->JP * 4;
     if (fine_grid)
-      hipLaunchKernelGGL((k_project_triplane_blk<1, true>), dim3(nbx * nby * nP), dim3(kTriThreads), lds_b, as_stream(s), heat_cl,
+      hipLaunchKernelGGL((k_project_triplane_blk<1, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
                          reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
-                         nbx, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
+                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
     else
-      hipLaunchKernelGGL((k_project_triplane_blk<1, false>), dim3(nbx * nby * nP), dim3(kTriThreads), lds_b, as_stream(s), heat_cl,
+      hipLaunchKernelGGL((k_project_triplane_blk<1, false>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
                          reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
-                         nbx, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
+                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
     return launch_status();
   }
   if (!gather && nvl <= 2) {

@@ -460,18 +460,31 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
 #ifndef FVP_TRI_BLK_OCC
 #define FVP_TRI_BLK_OCC 4
 #endif
+#ifndef FVP_TRI_BLK_BX
+#define FVP_TRI_BLK_BX 4            // x extent of the voxel block: 8 -> 512 threads, 4 -> 256 threads (finer phase interleaving)
+#endif
+// Block shape, measured (80 people, same box): 8 x 4 x 32 voxels / 512 threads 396 us; 4 x 4 x 32 / 256 threads 363 us (more,
+// smaller workgroups per CU: the plane-maxima phase of one lies beside the sampling of the others); 2 x 4 x 32 410 us;
+// 4 x 4 x 16 346-352 us.  Ablations of the 8 x 4 x 32 form: 395 us = 247 us sampling (10.5 GB of 64-byte taps: the L1's
+// 64 B/clk/CU line rate gives 268 us) + 81 us plane maxima + 67 us coordinates / tap descriptors.
+#ifndef FVP_TRI_BLK_BZ
+#define FVP_TRI_BLK_BZ 16
+#endif
+constexpr int kBlkBX = FVP_TRI_BLK_BX, kBlkBZ = FVP_TRI_BLK_BZ;
+constexpr int kBlkThreads = kBlkBX * kBY * 4 * 4;
 template <int NVL, bool CACHED>
-__global__ void __launch_bounds__(kTriThreads, FVP_TRI_BLK_OCC)
+__global__ void __launch_bounds__(kBlkThreads, FVP_TRI_BLK_OCC)
 k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
                        const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
                        const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
                        const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, FvpGeom g,
                        const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes) {
-  constexpr int BZ = NVL == 1 ? 32 : 16;
+  constexpr int BZ = NVL == 1 ? kBlkBZ : 16;
   constexpr int VPT = BZ / 4;
   constexpr int OWN = VPT / 4;
   HIP_DYNAMIC_SHARED(float, smem)                     // the block's plane cells (ints)
-  constexpr int NT = kTriThreads;
+  constexpr int NT = kBlkThreads;
+  constexpr int kBX = kBlkBX;                        // (shadows the staged kernels' block extent)
   const int J = g.J, JP = g.JP, CC = C * C, V = g.V, W = g.W, H = g.H;
   int p, blk;
   {
@@ -564,6 +577,9 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
         mine[k] = d;
       }
       if (CACHED && v + 1 < V) load_coords(v + 1);     // next view's coordinates under this view's sampling
+#ifdef FVP_TRI_BLK_NOSAMPLE
+      if (mine[0].base != -12345) { acc[0][0][0] += mine[0].w[0] + mine[OWN - 1].w[3] + float(mine[0].base); continue; }
+#endif
       const float* gsrc = frame + size_t(v) * view_stride;
       auto sample = [&](const TapL& tv, float (&a)[NVL][4]) {
 #pragma unroll
@@ -594,6 +610,9 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
         { const TapL tv = quad_bcast_l<3>(mine[k]); sample(tv, acc[4 * k + 3]); }
       }
     }
+#ifdef FVP_TRI_BLK_NOMAX          // (ablation variants, tools/build_variant.sh: wrong results)
+    if (acc[0][0][0] != 1.2345e-30f) continue;
+#endif
     // ---- block maxima through LDS, then into the global planes (as k_project_triplane_lds)
     int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JP]
     int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][BZ][JP]
@@ -618,6 +637,8 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
             atomicMax(&cyz[(yy * BZ + z) * JP + ch], __float_as_int(val));
           }
         }
+        // (reducing the four y lanes of an (x, z) cell with DPP row rotates before one of them touches LDS - lanes as
+        // q + 4 y + 16 zs - measured slower: 371 vs 361 us)
         int mi = __float_as_int(mz);
         mi = imax(mi, dpp_i<0x124>(mi));
         mi = imax(mi, dpp_i<0x128>(mi));
