@@ -812,7 +812,12 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   // the quad form's gather runs on the otherwise idle texture path beside the LDS reads of the staged rectangles).
   // FVP_TRI_TWO_TILE=0/1 overrides.
   const char* tt_env = fvp::diag_env("FVP_TRI_TWO_TILE");
-  const bool lane_form = !gather && !quad_form && g->JP <= 20 && g->JP != 16;
+  // Default for JP >= 16 (every shipped shape): the UNSTAGED compact-block form k_project_triplane_blk (round 4) - Panoptic
+  // 494 -> 348 us, Shelf 709 -> 592 us, Campus 161 -> 158 us against the LDS-staged forms, same bits.  The staged forms stay
+  // selectable in the diagnostics build (FVP_TRIPLANE_STAGED=1: quad form for JP = 16, lane-per-voxel form for JP = 20) and
+  // the lane-per-voxel form remains the default for JP <= 12 (miniature shapes: the quad lanes would idle).
+  const bool staged = fvp::diag_env("FVP_TRIPLANE_STAGED") != nullptr;
+  const bool lane_form = !gather && !quad_form && g->JP <= 20 && g->JP != 16 && (staged || g->JP < 16);
   const int tri_ablate = (tri_ablate_env & ~16) | ((tt_env ? atoi(tt_env) != 0 : lane_form) ? 16 : 0);
   // tests: FVP_TRI_CAP_PX lowers the rectangle size the kernel treats as fitting a tile (the allocation is unchanged),
   // so that one-tile, two-tile and global-gather rectangles all occur on small fixtures; read per call
@@ -852,7 +857,20 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   }
   // JP = 16 (Panoptic): the compact-block form WITHOUT LDS staging (k_project_triplane_blk, round 4).  FVP_TRIPLANE_STAGED=1
   // (diagnostics build) keeps the staged quad form for comparison; both give the same bits.
-  if (!gather && nvl == 1 && !quad_form && !fvp::diag_env("FVP_TRIPLANE_STAGED")) {
+  if (!gather && nvl == 2 && !quad_form && !staged) {
+    const int nbx2 = ceil_div(C, kBlkBX);
+    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * 16) * g->JP * 4;
+    if (fine_grid)
+      hipLaunchKernelGGL((k_project_triplane_blk<2, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
+                         reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
+                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
+    else
+      hipLaunchKernelGGL((k_project_triplane_blk<2, false>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
+                         reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
+                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
+    return launch_status();
+  }
+  if (!gather && nvl == 1 && !quad_form && !staged && g->JP == 16) {
     const int nbx2 = ceil_div(C, kBlkBX);
     const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * kBlkBZ) * g->JP * 4;
     if (fine_grid)
