@@ -66,16 +66,6 @@
 #ifndef FVP_WINO_IN_AUX
 #define FVP_WINO_IN_AUX 0
 #endif
-// Skewed chunk barrier (round 4): the second wave of every SIMD (waves NWV/2 .. NWV-1 of an 8-wave workgroup) takes the
-// chunk barrier ONE MFMA BURST EARLIER in its instruction stream - in front of the last step's first burst instead of its
-// second.  With the barrier at the same place for everybody the two waves of a SIMD leave it in lock-step: both issue a
-// burst (serialised on the one matrix pipe), then both run their patch transform while the pipe idles, every chunk.
-// Skewed, the late half arrives while the early half still owes one burst, so after the release one wave's vector work
-// always lies beside the other's MFMAs.  Safe because a wave's reads of the slot are complete at either place: the last
-// step's A(cout block 1) is requested at the top of half-step 0 and awaited (lgkmcnt(0)) before the early barrier.
-#ifndef FVP_WINO_SKEW
-#define FVP_WINO_SKEW 1
-#endif
 
 namespace fvp {
 
@@ -433,7 +423,6 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     }
     if (!(FVP_WINO_DIAG && (a.ablate & 128))) FVP_WINO_BARRIER();     // (bit 128, diagnostics: no chunk barrier)
   };
-  const bool early = FVP_WINO_SKEW && NWV == 8 && wave >= NWV / 2;   // wave-uniform: this wave takes the barrier one burst early
   // the chunk body exists twice: the unit's first chunk (its first step's MFMAs take C = 0) and every other one
   auto chunk = [&](int k, auto firstc) {
     constexpr bool kFirst = decltype(firstc)::value;
@@ -493,14 +482,6 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       FVP_TS(tC);
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (FVP_WINO_SKEW && s + 1 == S && early) {
-        // early barrier of the SIMD's second wave: every read of the slot (this step's patch, A of both cout blocks) has
-        // been requested; wait for them, then the slot is no longer needed by this wave
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        chunk_barrier(std::integral_constant<bool, kFirst>{}, more);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       mfma16(0, kFirst && s == 0);
       __builtin_amdgcn_sched_barrier(0);
       FVP_TS(tD);
@@ -513,7 +494,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       } else {
         // all reads of this slot are complete (lgkmcnt above); once every wave is here the slot
         // may be overwritten by the DMA of chunk g+3, and chunk g+1 has landed for everybody
-        if (!early) chunk_barrier(std::integral_constant<bool, kFirst>{}, more);
+        chunk_barrier(std::integral_constant<bool, kFirst>{}, more);
         if (k + 1 < nchunks) {                       // (a unit's last chunk: the epilogue needs the registers)
           fetch_a(0, wchunk(nxt, k + 1), 0);
           fetch_d(nxt, 0, wp);
