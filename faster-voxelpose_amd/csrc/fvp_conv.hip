@@ -901,6 +901,7 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
 
 }  // namespace fvp
 #include "fvp_conv_wino.h"
+#include "fvp_conv_reg.h"
 namespace fvp {
 
 // max_pool(2,2) / max_pool1d(2): one thread per output element.
@@ -1047,6 +1048,9 @@ static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
 static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const int kNoHeadFuse = int(env_size("FVP_CONV_NO_HEAD_FUSE", 0));
+static const int kNoReg = int(env_size("FVP_CONV_NO_REG", 0));     // diagnostics: 1x1 / transposed convs on k_conv_dma
+// (read per call in the diagnostics build, so that a test can run the same stack through both kernels; a constant in the product)
+static long reg_min_tiles() { return long(env_size("FVP_CONV_REG_MIN_TILES", 1024)); }
 static const int kNoKSplit = int(env_size("FVP_CONV_NO_KSPLIT", 0));   // diagnostics: no split-K form for the small-map 3x3 layers
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
 static const int kWinoGeneric = int(env_size("FVP_WINO_GENERIC", 0));
@@ -1204,6 +1208,67 @@ static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* pa
 #endif
 }
 
+template <int K, int NB, int MODE>
+static int launch_reg(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static LdsOptIn optin[2];
+  if (a.flags & FVP_EPI_RES) {
+    auto k = &k_conv_reg<K, NB, MODE, true>;
+    if (int e = lds_opt_in(optin[1], reinterpret_cast<const void*>(k), lds)) return e;
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  } else {
+    auto k = &k_conv_reg<K, NB, MODE, false>;
+    if (int e = lds_opt_in(optin[0], reinterpret_cast<const void*>(k), lds)) return e;
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  }
+  return launch_status();
+}
+
+// k_conv_reg (fvp_conv_reg.h) for 1x1 convs and paired transposed convs whose planes are whole 32-pixel tiles and whose
+// weights fit LDS.  Returns -1 when the layer is not of that kind (the caller goes on to k_conv_dma).  The two kernels
+// produce the same bits, so the choice may depend on the amount of work: below reg_min_tiles() tiles (a few planes of
+// CenterNet's maps) the 256-pixel tiles of k_conv_dma spread over more CUs.
+static int plan_and_launch_reg(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s, bool tr) {
+  const int hw = op.h * op.w;
+  if (kNoReg || op.cin != op.cinp || op.h <= 1 || hw % 32) return -1;
+  const long tiles = long(planes) * (hw / 32);
+  if (tiles < reg_min_tiles()) return -1;
+  int mode = 0, NB = op.coutp / 32;
+  a.wrow = op.coutp;
+  if (tr) {
+    if (op.pair_off <= 0 || kNoPair) return -1;
+    mode = a.w2 ? 2 : 1;
+    NB = 2 * op.coutp / 32;
+    a.wts = params + op.pair_off;
+    a.wrow = 2 * op.coutp;
+    a.ntapT = 2;
+    a.tapT_w = 1;
+  } else if (op.kh != 1 || op.kw != 1 || a.w2) {
+    return -1;
+  }
+  const int key = op.cinp * 100 + NB * 10 + mode;
+  if (key != 1610 && key != 3210 && key != 3220 && key != 6440 && key != 12841 && key != 6421 && key != 6422) return -1;
+  a.m_tpp = make_magic(hw / 32);
+  a.m_w = make_magic(op.w);
+  a.zeros = params;
+  const size_t lds = (size_t(op.cinp) * 32 * NB + 3 * size_t(op.coutp) + (mode == 2 ? 32 * 32 + 96 : 0)) * sizeof(float);
+  const int occ = op.cinp * NB <= 128 ? 3 : 2;
+  const int per_cu = std::max(1, std::min(occ, int((160 * 1024) / (lds + 256))));
+  const int nz = tr ? 2 : 1;
+  const long want = (tiles + 3) / 4;
+  const int gx = int(std::min<long>(want, std::max(1, persistent_workgroups() * per_cu / nz)));
+  dim3 grid(gx, 1, nz);
+  ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * (tr ? 4.0 : 1.0) * hw * planes, 1, prof_level() >= 2);
+  switch (key) {
+    case 1610: return launch_reg<16, 1, 0>(a, grid, lds, s);
+    case 3210: return launch_reg<32, 1, 0>(a, grid, lds, s);
+    case 3220: return launch_reg<32, 2, 0>(a, grid, lds, s);
+    case 6440: return launch_reg<64, 4, 0>(a, grid, lds, s);
+    case 12841: return launch_reg<128, 4, 1>(a, grid, lds, s);
+    case 6421: return launch_reg<64, 2, 1>(a, grid, lds, s);
+    default: return launch_reg<64, 2, 2>(a, grid, lds, s);
+  }
+}
+
 // ConvTranspose(k2,s2) in the paired form: CB = 2*coutp/32 accumulator blocks (both column taps),
 // grid.z = output row parity.
 static int plan_and_launch_tpair(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
@@ -1299,6 +1364,10 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   a.OW = op.w * a.osx;
   if (double(planes) * std::max(op.cin, op.cout) * a.OH * a.OW >= 2147483648.0) return FVP_ELIMIT;
   a.wrow = op.coutp;
+  if (tr || (kh == 1 && kw == 1)) {
+    const int rc = plan_and_launch_reg(op, a, params, planes, s, tr);
+    if (rc != -1) return rc;
+  }
   if (tr && op.h > 1 && op.pair_off > 0 && !kNoPair && op.w % 4 == 0 && (op.coutp == 32 || op.coutp == 64))
     return plan_and_launch_tpair(op, a, params, planes, s);
   const int CBfull = op.coutp / 32;

@@ -220,3 +220,54 @@ def split_k_stack(cin, cmid, hw, seed=0):
         h1 = F.relu(F.conv2d(x, w["a.weight"].double(), w["a.bias"].double(), padding=1))
         return F.relu(F.conv2d(h1, w["b.weight"].double(), w["b.bias"].double(), padding=1) + h1)
     return spec, w, ref, o
+
+
+def reg_stack(seed=0, fused_head=True):
+    """1x1 convs and transposed convs with P2PNet's channel counts on 16x16 / 8x8 maps (whole 32-pixel tiles): the layers
+    k_conv_reg takes.  x [planes, 32, 16, 16] -> 1x1 32->64, pool, 1x1 64->128, up 128->64 (+ skip), up 64->32 (+ skip),
+    1x1 32->15 (fused into the second transposed conv when it is that conv's only consumer), 1x1 16->32 on a slice-free
+    side branch.  Returns spec, weights, float64 torch reference (dict of outputs), output buffer ids."""
+    import torch.nn.functional as F
+
+    from faster_voxelpose_amd import netspec
+    spec = netspec.StackSpec(2, 32, (16, 16))
+    spec._conv_entries("s64", 32, 64, 1)
+    spec._conv_entries("t128", 64, 128, 1)
+    spec._conv_entries("u64", 128, 64, 2, transposed=True)
+    spec._conv_entries("u32", 64, 32, 2, transposed=True)
+    spec._conv_entries("head", 32, 15, 1)
+    spec._conv_entries("d16", 32, 16, 3)
+    spec._conv_entries("s32", 16, 32, 1)
+    s64 = spec.conv("s64", None, 0, 64, 1, relu=False)
+    p = spec.pool(s64)
+    t128 = spec.conv("t128", None, p, 128, 1, relu=True)
+    u64 = spec.up("u64", None, t128, 64, s64)
+    u32 = spec.up("u32", None, p, 32, 0)
+    head = spec.conv("head", None, u32, 15, 1, relu=False)
+    d16 = spec.conv("d16", None, u32 if not fused_head else 0, 16, 3, relu=True)
+    s32 = spec.conv("s32", None, d16, 32, 1, relu=False, res=0)
+    spec.outputs.update(u64=u64, head=head, s32=s32)
+    spec.finalize()
+    g = torch.Generator().manual_seed(seed)
+
+    def wb(key, cout, cin, k, transposed=False):
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        return {key + ".weight": torch.randn(shape, generator=g) / (cin * k * k) ** 0.5, key + ".bias": torch.randn(cout, generator=g) * 0.1}
+    w = {}
+    for args in (("s64", 64, 32, 1), ("t128", 128, 64, 1), ("u64", 64, 128, 2, True), ("u32", 32, 64, 2, True),
+                 ("head", 15, 32, 1), ("d16", 16, 32, 3), ("s32", 32, 16, 1)):
+        w.update(wb(*args))
+
+    def ref(x):
+        x = x.double()
+        W = {k: v.double() for k, v in w.items()}
+        a = F.conv2d(x, W["s64.weight"], W["s64.bias"])
+        pp = F.max_pool2d(a, 2)
+        t = F.relu(F.conv2d(pp, W["t128.weight"], W["t128.bias"]))
+        o_u64 = F.relu(F.conv_transpose2d(t, W["u64.weight"], W["u64.bias"], stride=2)) + a
+        o_u32 = F.relu(F.conv_transpose2d(pp, W["u32.weight"], W["u32.bias"], stride=2)) + x
+        o_head = F.conv2d(o_u32, W["head.weight"], W["head.bias"])
+        d = F.relu(F.conv2d(o_u32 if not fused_head else x, W["d16.weight"], W["d16.bias"], padding=1))
+        o_s32 = F.conv2d(d, W["s32.weight"], W["s32.bias"]) + x
+        return dict(u64=o_u64, head=o_head, s32=o_s32)
+    return spec, w, ref, dict(u64=u64, head=head, s32=s32)

@@ -13,7 +13,7 @@ import torch
 
 import fvp_oracle as O
 from cases import make_inputs, make_weights
-from common import check_outputs, load_golden, run_custom_conv_stack, split_k_stack
+from common import check_outputs, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
 import fvp_synthetic as S
 from faster_voxelpose_amd.models import faster_voxelpose as FV
 
@@ -258,6 +258,23 @@ def test_split_k_direct_conv_on_small_maps(emu_lib, cin, cmid, hw, planes):
     got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)[o]
     want = ref(x)
     np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("fused_head", [True, False])
+def test_register_direct_conv_equals_the_staged_kernel(emu_lib, monkeypatch, fused_head):
+    """k_conv_reg (1x1 convs, transposed convs, transposed conv + fused 1x1 head: activations straight from the map into
+    MFMA operands, weights resident in LDS) against k_conv_dma on the same stack: the same bits (same ascending-channel
+    MFMA chain), and both against a float64 torch evaluation.  Five planes: the last workgroup's waves run out of tiles."""
+    spec, w, ref, outs = reg_stack(seed=3, fused_head=fused_head)
+    x = torch.from_numpy(np.random.default_rng(9).normal(size=(5, 32, 16, 16)).astype(np.float32))
+    monkeypatch.setenv("FVP_CONV_REG_MIN_TILES", "1")
+    got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)
+    monkeypatch.setenv("FVP_CONV_REG_MIN_TILES", "1000000000")
+    staged = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)
+    want = ref(x)
+    for name, o in outs.items():
+        assert torch.equal(got[o], staged[o]), name
+        np.testing.assert_allclose(got[o].double().numpy(), want[name].numpy(), rtol=2e-5, atol=2e-5, err_msg=name)
 
 
 @pytest.mark.parametrize("quad", [False, True])
