@@ -1230,6 +1230,7 @@ static int launch_reg(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
 static int plan_and_launch_reg(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s, bool tr) {
   const int hw = op.h * op.w;
   if (kNoReg || op.cin != op.cinp || op.h <= 1 || hw % 32) return -1;
+  if ((op.flags & FVP_EPI_RES) && op.cout % 8) return -1;         // (residual rows are read through a uniform row pointer)
   const long tiles = long(planes) * (hw / 32);
   if (tiles < reg_min_tiles()) return -1;
   int mode = 0, NB = op.coutp / 32;
@@ -1245,18 +1246,21 @@ static int plan_and_launch_reg(const FvpConvOp& op, ConvArgs a, const float* par
   } else if (op.kh != 1 || op.kw != 1 || a.w2) {
     return -1;
   }
+  const int ny = 1;
   const int key = op.cinp * 100 + NB * 10 + mode;
   if (key != 1610 && key != 3210 && key != 3220 && key != 6440 && key != 12841 && key != 6421 && key != 6422) return -1;
   a.m_tpp = make_magic(hw / 32);
   a.m_w = make_magic(op.w);
   a.zeros = params;
+  a.ablate = kAblate;
   const size_t lds = (size_t(op.cinp) * 32 * NB + 3 * size_t(op.coutp) + (mode == 2 ? 32 * 32 + 96 : 0)) * sizeof(float);
-  const int occ = op.cinp * NB <= 128 ? 3 : 2;
+  static const int kRegWgs = int(env_size("FVP_CONV_REG_WGS", 0));   // diagnostics: workgroups per CU
+  const int occ = kRegWgs ? kRegWgs : (op.cinp * NB <= 128 ? 3 : 2);
   const int per_cu = std::max(1, std::min(occ, int((160 * 1024) / (lds + 256))));
   const int nz = tr ? 2 : 1;
   const long want = (tiles + 3) / 4;
-  const int gx = int(std::min<long>(want, std::max(1, persistent_workgroups() * per_cu / nz)));
-  dim3 grid(gx, 1, nz);
+  const int gx = int(std::min<long>(want, std::max(1, persistent_workgroups() * per_cu / (nz * ny))));
+  dim3 grid(gx, ny, nz);
   ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * (tr ? 4.0 : 1.0) * hw * planes, 1, prof_level() >= 2);
   switch (key) {
     case 1610: return launch_reg<16, 1, 0>(a, grid, lds, s);

@@ -7,8 +7,13 @@
 // straight from the NCHW map into registers (128-byte rows per half wave), all K / 2 of them before the first MFMA.
 // The weights of the whole layer sit in LDS once per workgroup (persistent workgroups walk the tile list), so the main
 // loop has no barrier, no DMA bookkeeping and no staging arithmetic: per MFMA one half of an 8-byte LDS read.
-// k_conv_dma on these layers is three serial phases per tile (stage, MFMA, epilogue: 17 + 27 + 25 us on the 128 -> 64
-// transposed conv); here the phases of a SIMD's two or three waves overlap freely.
+// The next tile's operands are requested before this tile's epilogue (and the first tile's before the weights are staged),
+// the small instances also fetch a tile's residual values before its MFMA loop.
+// Measured on the MI355X, B = 8 (240 planes), k_conv_dma -> this kernel: 1x1 skips 40.6 / 29.1-32.6 / 25.1 -> 34.3 / 23.1 /
+// 19.3-21 us, transposed 128 -> 64: 72.9 -> 61 us, transposed 64 -> 32 + fused 1x1 head: 125 -> 76-80 us (the head as MFMAs
+// instead of a 32-step fma chain with lane hops).  What is left (128 -> 64: loads 10 + MFMA 29-33 + epilogue 21 us, measured
+// one phase at a time) still ADDS UP: one, two or three waves per SIMD, distinct issue priorities per wave slot, a staggered
+// start of every other workgroup and a cout split over two workgroups all measured within +-3 us of each other.
 //
 //   Wl[q][h][n] = float2{ W[4 q + h][n], W[4 q + 2 + h][n] }   (h = lane >> 5): one ds_read_b64 feeds MFMA steps 2 q and
 //   2 q + 1; a half wave reads 256 contiguous bytes: conflict-free without padding.
@@ -20,19 +25,61 @@
 // them into B operands for channel pairs (2 t, 2 t + 1), consumed in ascending t: the chain of the standalone 1x1 kernel.
 #pragma once
 
+// prefetch policy (bit 0: the next tile's B operands before this tile's epilogue, bit 1: this tile's residual values before
+// its MFMA loop) and waves per SIMD, for the instances with >= 256 / < 256 accumulator-plus-operand registers
+#ifndef FVP_REG_PF_BIG
+#define FVP_REG_PF_BIG 1
+#endif
+#ifndef FVP_REG_PF_SMALL
+#define FVP_REG_PF_SMALL 3
+#endif
+#ifndef FVP_REG_OCC_SMALL
+#define FVP_REG_OCC_SMALL 3
+#endif
+
 namespace fvp {
 
 template <int K, int NB, int MODE, bool HAS_RES>
-__global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvArgs a) {
+__global__ void __launch_bounds__(256, (K * NB <= 128 ? FVP_REG_OCC_SMALL : 2)) k_conv_reg(ConvArgs a) {
+  constexpr int PF = (K * NB >= 256) ? FVP_REG_PF_BIG : FVP_REG_PF_SMALL;
+  constexpr bool PFB = PF & 1, PFR = HAS_RES && (PF & 2);
   HIP_DYNAMIC_SHARED(float, smem)
   static_assert(K % 4 == 0 && K >= 4, "channel quads");
   static_assert(MODE == 0 || NB % 2 == 0, "the transposed conv keeps both column taps of a cout block");
   static_assert(MODE != 2 || NB == 2, "the fused 1x1 conv needs all 32 couts of a pixel in one lane pair");
   constexpr int NT = 32 * NB;                         // floats per packed weight row
   constexpr int KQ = K / 4;
+  constexpr int NR = MODE ? NB / 2 : NB;              // residual / output register blocks of a tile
   const int t = threadIdx.x, lane = t & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int dy = MODE ? int(blockIdx.z) : 0;
+  const int co0 = blockIdx.y * (MODE ? NT / 2 : NT);  // first cout of this workgroup
+  const int W = a.W, HW = a.H * W;
+  const int tpp = HW >> 5;                            // tiles per plane (host: HW % 32 == 0)
+  const int ntiles = a.planes * tpp;
+  const int stride = gridDim.x * 4;
+
+  // tiles of masked planes are skipped (k_conv_dma: whole workgroups return)
+  auto next_valid = [&](int tl) {
+    if (a.plane_valid)
+      while (tl < ntiles && !a.plane_valid[fdiv(tl, a.m_tpp) / a.valid_div]) tl += stride;
+    return tl;
+  };
+  // every global access of the loop is "uniform row pointer + one per-lane 32-bit offset" (scalar base, one offset
+  // register for all K / 2 loads resp. all rows of the tile): 64-bit per-lane addresses cost two registers per load in flight
+  const unsigned voff_in = unsigned(half * HW + l31);
+  float b[K / 2];
+#pragma unroll
+  for (int s = 0; s < K / 2; ++s) b[s] = 0.0f;           // (only read un-loaded under the diagnostics ablation)
+  auto load_b = [&](int tl) {
+    const int pl = fdiv(tl, a.m_tpp);
+    const float* sp = a.src + size_t(pl) * K * HW + (tl - pl * tpp) * 32;
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) b[s] = (sp + size_t(2 * s) * HW)[voff_in];
+  };
+  // the first tile's operands are on their way while the weights are staged
+  int tile = next_valid(blockIdx.x * 4 + wave);
+  if (PFB && tile < ntiles && !(a.ablate & 1)) load_b(tile);
 
   float2* Wl = reinterpret_cast<float2*>(smem);
   float* epi_s = smem + K * NT;
@@ -40,9 +87,17 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvA
   float* epi2_s = epi_s + 3 * a.coutp + 32 * 32;
   {
     const float* wts = a.wts + size_t(dy) * K * a.wrow;
-    for (int i = t; i < KQ * 2 * NT; i += 256) {
-      const int n = i % NT, qh = i / NT, h = qh & 1, q = qh >> 1;
-      Wl[i] = make_float2(wts[(4 * q + h) * a.wrow + n], wts[(4 * q + 2 + h) * a.wrow + n]);
+    constexpr int NQ4 = NT / 4;
+#pragma unroll 4
+    for (int i = t; i < ((a.ablate & 2) ? 0 : KQ * 2 * NQ4); i += 256) {
+      const int n4 = i % NQ4, qh = i / NQ4, h = qh & 1, q = qh >> 1;
+      // column of packed row element n: this workgroup's cout block (blockIdx.y) of the 1x1 conv, or of each column tap
+      const int n = 4 * n4, col = MODE ? (n / (NT / 2)) * a.coutp + co0 + n % (NT / 2) : co0 + n;
+      const float4 u = *reinterpret_cast<const float4*>(wts + (4 * q + h) * a.wrow + col);
+      const float4 v = *reinterpret_cast<const float4*>(wts + (4 * q + 2 + h) * a.wrow + col);
+      float4* d = reinterpret_cast<float4*>(Wl + qh * NT + 4 * n4);
+      d[0] = make_float4(u.x, v.x, u.y, v.y);
+      d[1] = make_float4(u.z, v.z, u.w, v.w);
     }
     for (int i = t; i < 3 * a.coutp; i += 256) epi_s[i] = a.epi[i];
     if (MODE == 2) {
@@ -55,24 +110,44 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvA
   }
   __syncthreads();
 
-  const int W = a.W, HW = a.H * W;
-  const int tpp = HW >> 5;                            // tiles per plane (host: HW % 32 == 0)
-  const int ntiles = a.planes * tpp;
   const float* bias = epi_s;
   const float* scale = epi_s + a.coutp;
   const float* shift = epi_s + 2 * a.coutp;
   const bool relu = a.flags & FVP_EPI_RELU;
   const bool res_after = a.flags & FVP_EPI_RES_AFTER_RELU;
   const float2* wl = Wl + half * NT + l31;
+  const int OHW = a.OH * a.OW;
 
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  while (tile < ntiles) {
     const int plane = fdiv(tile, a.m_tpp);
-    if (a.plane_valid && !a.plane_valid[plane / a.valid_div]) continue;
     const int px = (tile - plane * tpp) * 32 + l31;
-    const float* xp = a.src + (size_t(plane) * K + half) * HW + px;
-    float b[K / 2];
+    // per-lane part of an output address: the pixel, and 4 rows further for the upper half wave; row (r, nb) adds a uniform
+    // (nb * 32 + (r & 3) + 8 (r >> 2)) * ostep.  (host: cout % 8 == 0 when there is a residual, so a clamped row + 4 stays inside)
+    unsigned ostep, voff;
+    if (MODE == 0) {
+      ostep = unsigned(HW);
+      voff = unsigned(px) + 4u * unsigned(half) * ostep;
+    } else {
+      const int y = fdiv(px, a.m_w), x = px - y * W;
+      ostep = unsigned(OHW);
+      voff = unsigned((2 * y + dy) * a.OW + 2 * x) + 4u * unsigned(half) * ostep;
+    }
+    const size_t pbase = size_t(plane) * a.cout * ostep;
+    typedef typename std::conditional<MODE == 0, float, float2>::type res_t;
+    res_t rv[PFR ? NR : 1][16];
+    auto load_res = [&](int nb, res_t (&dst)[16]) {
 #pragma unroll
-    for (int s = 0; s < K / 2; ++s) b[s] = xp[size_t(2 * s) * HW];
+      for (int r = 0; r < 16; ++r) {
+        const int cu = co0 + nb * 32 + (r & 3) + 8 * (r >> 2);
+        const float* rowp = a.res + pbase + size_t(cu < a.cout ? cu : 0) * ostep;
+        dst[r] = *reinterpret_cast<const res_t*>(rowp + voff);
+      }
+    };
+    if (PFR) {
+#pragma unroll
+      for (int nb = 0; nb < NR; ++nb) load_res(nb, rv[nb]);
+    }
+    if (!PFB && !(a.ablate & 1)) load_b(tile);
 
     f32x16 acc[NB];
 #pragma unroll
@@ -83,6 +158,7 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvA
     float2 av[2][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) av[0][nb] = wl[nb * 32];
+    if (!(a.ablate & 4))
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const int cur = q & 1;
@@ -99,54 +175,43 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvA
       for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][nb].y, b[2 * q + 1], acc[nb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // the next tile's operands travel during this tile's epilogue (and the other waves' MFMA loops)
+    const int nxt = next_valid(tile + stride);
+    if (PFB && nxt < ntiles && !(a.ablate & 1)) load_b(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.ablate & 8) {
+      tile = nxt;
+      continue;
+    }
 
     if constexpr (MODE == 0) {
-      const unsigned obase = unsigned(plane) * unsigned(a.cout) * unsigned(HW) + unsigned(px);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float rv[16];
-        unsigned o[16];
-        bool ok[16];
+        res_t rl[16];
+        if (HAS_RES && !PFR) load_res(nb, rl);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          ok[r] = co < a.cout;
-          o[r] = obase + unsigned(ok[r] ? co : 0) * unsigned(HW);
-          if (HAS_RES) rv[r] = a.res[o[r]];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // < coutp: epi vectors are padded
+          const int co = co0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // < coutp: epi vectors are padded
           float v = bn_affine(acc[nb][r], bias[co], scale[co], shift[co]);
-          if (HAS_RES && !res_after) v += rv[r];
+          const float rr = HAS_RES ? (PFR ? rv[PFR ? nb : 0][r] : rl[r]) : 0.f;
+          if (HAS_RES && !res_after) v += rr;
           if (relu) v = fmaxf(v, 0.0f);
-          if (HAS_RES && res_after) v += rv[r];
-          if (ok[r]) a.dst[o[r]] = v;
+          if (HAS_RES && res_after) v += rr;
+          if (co < a.cout) (a.dst + pbase + size_t(co - 4 * half) * ostep)[voff] = v;
         }
       }
     } else {
       constexpr int CH = NB / 2;
-      const int OHW = a.OH * a.OW;
-      const int y = fdiv(px, a.m_w), x = px - y * W;
-      const unsigned pix = unsigned((2 * y + dy) * a.OW + 2 * x);
-      const unsigned pbase = unsigned(plane) * unsigned(a.cout);
 #pragma unroll
       for (int cb = 0; cb < CH; ++cb) {
-        float2 rv[16];
-        unsigned o[16];
-        bool ok[16];
+        res_t rl[16];
+        if (HAS_RES && !PFR) load_res(cb, rl);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          ok[r] = co < a.cout;
-          o[r] = (pbase + unsigned(ok[r] ? co : 0)) * unsigned(OHW) + pix;
-          if (HAS_RES) rv[r] = *reinterpret_cast<const float2*>(a.res + o[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v[2] = {acc[cb][r], acc[cb + CH][r]};
-          const float rr[2] = {HAS_RES ? rv[r].x : 0.f, HAS_RES ? rv[r].y : 0.f};
+          const res_t r2 = HAS_RES ? (PFR ? rv[PFR ? cb : 0][r] : rl[r]) : res_t{};
+          const float rr[2] = {r2.x, r2.y};
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             float xv = bn_affine(v[e], bias[co], scale[co], shift[co]);
@@ -158,8 +223,8 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvA
           if (MODE == 2) {
             acc[cb][r] = v[0];                         // B operands of the fused 1x1 conv
             acc[cb + CH][r] = v[1];
-          } else if (ok[r]) {
-            *reinterpret_cast<float2*>(a.dst + o[r]) = make_float2(v[0], v[1]);
+          } else if (co < a.cout) {
+            *reinterpret_cast<float2*>(a.dst + pbase + size_t(co - 4 * half) * ostep + voff) = make_float2(v[0], v[1]);
           }
         }
       }
@@ -192,7 +257,7 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvA
         const float* scale2 = epi2_s + 32;
         const float* shift2 = epi2_s + 64;
         const bool relu2 = a.flags2 & FVP_EPI_RELU;
-        const unsigned pb2 = unsigned(plane) * unsigned(a.cout2);
+        const size_t pbase2 = size_t(plane) * a.cout2 * ostep;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -201,10 +266,11 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? 3 : 2)) k_conv_reg(ConvA
             x0 = fmaxf(x0, 0.0f);
             x1 = fmaxf(x1, 0.0f);
           }
-          if (j < a.cout2) *reinterpret_cast<float2*>(a.dst2 + (pb2 + unsigned(j)) * unsigned(OHW) + pix) = make_float2(x0, x1);
+          if (j < a.cout2) *reinterpret_cast<float2*>(a.dst2 + pbase2 + size_t(j - 4 * half) * ostep + voff) = make_float2(x0, x1);
         }
       }
     }
+    tile = nxt;
   }
 }
 

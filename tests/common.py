@@ -175,7 +175,7 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
     np.testing.assert_allclose(pl, g["plane_poses"], rtol=0, atol=tol)
 
 
-def run_custom_conv_stack(lib, device, spec, weights, x, stream=None):
+def run_custom_conv_stack(lib, device, spec, weights, x, stream=None, plane_valid=None):
     """Run a hand-made ``netspec.StackSpec`` (finalized) through fvp_pack_conv + fvp_conv_stack_run.
     ``weights``: {key + '.weight' / '.bias': tensor}; ``x``: [planes, C, H, W].  Returns every activation buffer."""
     import ctypes as C
@@ -193,8 +193,9 @@ def run_custom_conv_stack(lib, device, spec, weights, x, stream=None):
     planes = x.shape[0]
     bufs = [x.to(device).contiguous()] + [torch.empty((planes,) + tuple(b), device=device) for b in spec.bufs[1:]]
     arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+    pv = None if plane_valid is None else plane_valid.to(device=device, dtype=torch.uint8).contiguous()
     capi.check(lib, lib.fvp_conv_stack_run(spec.op_array, len(spec.ops), C.c_void_p(blob.data_ptr()), arr, len(bufs), planes,
-                                           None, 1, s), "fvp_conv_stack_run")
+                                           None if pv is None else C.c_void_p(pv.data_ptr()), 1, s), "fvp_conv_stack_run")
     return bufs
 
 

@@ -269,11 +269,14 @@ def test_register_direct_conv_equals_the_staged_kernel(emu_lib, monkeypatch, fus
     x = torch.from_numpy(np.random.default_rng(9).normal(size=(5, 32, 16, 16)).astype(np.float32))
     monkeypatch.setenv("FVP_CONV_REG_MIN_TILES", "1")
     got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)
+    valid = torch.tensor([1, 0, 1, 1, 0], dtype=torch.uint8)            # masked planes: their tiles are skipped
+    masked = run_custom_conv_stack(emu_lib, "cpu", spec, w, x, plane_valid=valid)
     monkeypatch.setenv("FVP_CONV_REG_MIN_TILES", "1000000000")
     staged = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)
     want = ref(x)
     for name, o in outs.items():
         assert torch.equal(got[o], staged[o]), name
+        assert torch.equal(masked[o][valid.bool()], got[o][valid.bool()]), name
         np.testing.assert_allclose(got[o].double().numpy(), want[name].numpy(), rtol=2e-5, atol=2e-5, err_msg=name)
 
 

@@ -10,7 +10,7 @@ import torch
 
 import fvp_oracle as O
 from cases import CASES, make_inputs, make_weights
-from common import check_outputs, load_golden, run_custom_conv_stack, split_k_stack
+from common import check_outputs, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
 import fvp_synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -191,6 +191,27 @@ def test_split_k_direct_conv_on_small_maps(cin, cmid, hw, planes):
     np.testing.assert_allclose(got.double().numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5)
     one = run_custom_conv_stack(lib, DEV, spec, w, x[planes - 1:], st)[o].cpu()
     assert torch.equal(one[0], got[planes - 1])
+
+
+@pytest.mark.parametrize("fused_head", [True, False])
+def test_register_direct_conv_is_batch_independent(fused_head):
+    """1x1 convs / transposed convs (+ fused 1x1 head): 600 planes take k_conv_reg (>= 1024 tiles of 32 pixels on both map
+    sizes), 3 planes take k_conv_dma - a plane's result must not depend on that (same MFMA chain: bit-identical), with a
+    third of the planes masked out as well, and both match a float64 torch evaluation."""
+    from faster_voxelpose_amd import _capi as capi
+    lib = capi.load()
+    spec, w, ref, outs = reg_stack(seed=4, fused_head=fused_head)
+    x = torch.from_numpy(np.random.default_rng(6).normal(size=(600, 32, 16, 16)).astype(np.float32))
+    st = torch.cuda.current_stream().cuda_stream
+    big = run_custom_conv_stack(lib, DEV, spec, w, x, st)
+    few = run_custom_conv_stack(lib, DEV, spec, w, x[:3], st)
+    valid = (torch.arange(600) % 3 != 1).to(torch.uint8)
+    masked = run_custom_conv_stack(lib, DEV, spec, w, x, st, plane_valid=valid)
+    want = ref(x[:8])
+    for name, o in outs.items():
+        assert torch.equal(big[o][:3].cpu(), few[o].cpu()), name
+        assert torch.equal(masked[o].cpu()[valid.bool()], big[o].cpu()[valid.bool()]), name
+        np.testing.assert_allclose(big[o][:8].cpu().double().numpy(), want[name].numpy(), rtol=2e-5, atol=2e-5, err_msg=name)
 
 
 def test_conv_stacks_vs_torch_fp32():

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="", help="comma-separated op indices (default: all)")
+    ap.add_argument("--span", default="", help="a:b - additionally time ops a..b-1 as ONE stack run (fusions apply)")
     args = ap.parse_args()
     dev = "cuda:0"
     cfg = S.make_cfg("panoptic", device=dev, min_score=-1.0)
@@ -65,6 +66,18 @@ def main():
         print(f"  op{i:2d} {kind:5s} {op['cin']:3d}->{op['cout']:3d} k{op['kh']}x{op['kw']} @{op['h']}x{op['w']}  "
               f"{us:8.1f} us  {fl / us / 1e6:6.1f} TF/s  {byt / us / 1e3:7.1f} GB/s")
     print(f"  total {tot:.1f} us per pass = {tot / args.frames:.1f} us/frame")
+    if args.span:
+        lo, hi = (int(x) for x in args.span.split(":"))
+        sub = (capi.FvpConvOp * (hi - lo))(*[spec.op_array[i] for i in range(lo, hi)])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(args.iters + 1):
+            if it == 1:
+                a.record()
+            capi.check(lib, lib.fvp_conv_stack_run(sub, hi - lo, _ptr(e.params[args.net]), arr, len(bufs), planes, None, 1,
+                                                   e.stream()), "run")
+        b.record()
+        torch.cuda.synchronize()
+        print(f"  span {lo}:{hi} as one stack  {a.elapsed_time(b) * 1e3 / args.iters:8.1f} us")
 
 
 if __name__ == "__main__":

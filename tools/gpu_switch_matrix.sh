@@ -12,4 +12,6 @@ run FVP_TRIPLANE_QUAD=1 FVP_TRI_TWO_TILE=1 FVP_TRI_CAP_PX=200
 run FVP_TRIPLANE_GATHER=1
 run FVP_CONV_NO_KSPLIT=1 FVP_CONV_NO_HEAD_FUSE=1 FVP_CONV_NO_POOL_FUSE=1
 run FVP_CONV_NO_WINO=1
+run FVP_CONV_NO_REG=1
+run FVP_CONV_REG_MIN_TILES=1
 run FVP_WINO_HALF=1
