@@ -1050,7 +1050,9 @@ static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const int kNoHeadFuse = int(env_size("FVP_CONV_NO_HEAD_FUSE", 0));
 static const int kNoReg = int(env_size("FVP_CONV_NO_REG", 0));     // diagnostics: 1x1 / transposed convs on k_conv_dma
 // (read per call in the diagnostics build, so that a test can run the same stack through both kernels; a constant in the product)
-static long reg_min_tiles() { return long(env_size("FVP_CONV_REG_MIN_TILES", 1024)); }
+// Transposed convs gain from 200 tiles on (B = 1: 128 -> 64 22.6 -> 18.6 us at 240 tiles, 64 -> 32 17.2 -> 12.5 us at 960; CenterNet at
+// B = 8: 16.3 -> 9.0 us at 400), 1x1 convs only from ~1 000 (64 -> 128 at 240 tiles: 7.4 -> 13.1 us).
+static long reg_min_tiles(bool transposed) { return long(env_size("FVP_CONV_REG_MIN_TILES", transposed ? 200 : 1024)); }
 static const int kNoKSplit = int(env_size("FVP_CONV_NO_KSPLIT", 0));   // diagnostics: no split-K form for the small-map 3x3 layers
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
 static const int kWinoGeneric = int(env_size("FVP_WINO_GENERIC", 0));
@@ -1232,7 +1234,7 @@ static int plan_and_launch_reg(const FvpConvOp& op, ConvArgs a, const float* par
   if (kNoReg || op.cin != op.cinp || op.h <= 1 || hw % 32) return -1;
   if ((op.flags & FVP_EPI_RES) && op.cout % 8) return -1;         // (residual rows are read through a uniform row pointer)
   const long tiles = long(planes) * (hw / 32);
-  if (tiles < reg_min_tiles()) return -1;
+  if (tiles < reg_min_tiles(tr)) return -1;
   int mode = 0, NB = op.coutp / 32;
   a.wrow = op.coutp;
   if (tr) {

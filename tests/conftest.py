@@ -26,7 +26,7 @@ def emu_lib():
     # them: read once when the library loads, mirrored on the host side by netspec.WINO_GENERIC (weight-blob layout).
     os.environ.setdefault("FVP_WINO_GENERIC", "1")
     # the register-direct 1x1 / transposed-conv kernel also takes the few planes of the emulated cases (the product keeps
-    # k_conv_dma below 1024 tiles; the two kernels produce the same bits: test_register_direct_conv_equals_the_staged_kernel)
+    # k_conv_dma below 1024 (1x1) / 200 (transposed) tiles; the two kernels produce the same bits: test_register_direct_conv_equals_the_staged_kernel)
     os.environ.setdefault("FVP_CONV_REG_MIN_TILES", "1")
     netspec.WINO_GENERIC = True
     here = os.path.join(ROOT, "tests", "hipemu")
