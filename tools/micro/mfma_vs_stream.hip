@@ -14,6 +14,7 @@ template <int MODE, bool SPLIT, int PRIO = 0, bool AGPR = false, int KIND = 0>
 __global__ void __launch_bounds__(512, 1) kms(const float* __restrict__ src, float* __restrict__ dst, float* out, int tiles_per_wave,
                                                int mfma_per_tile, int rows, size_t row_stride, float a0) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const long long t0 = clock64();
   const bool do_m = (MODE & 1) && (!SPLIT || wave < 4);
   const bool do_s = (MODE & 2) && (!SPLIT || wave >= 4);
   if (PRIO == 1 && SPLIT && wave >= 4) __builtin_amdgcn_s_setprio(3);   // stream waves above the MFMA waves
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(512, 1) kms(const float* __restrict__ src, flo
 #pragma unroll
   for (int i = 0; i < 4; ++i) sum += acc[i][0];
   if (sum == 123.456f) out[0] = sum;
+  if (blockIdx.x == 7 && lane == 0) out[8 + wave] = float(clock64() - t0);
 }
 
 template <int MODE, bool SPLIT, int PRIO = 0, bool AGPR = false, int KIND = 0>
@@ -173,6 +175,13 @@ int main() {
   }
   printf("interleaved (every wave: 4 MFMAs, 1 load, 1 store, ...; 128 MFMA + 32 rows per tile): mfma %.1f us, stream %.1f us, both %.1f us\n",
          run_int<1>(src, dst, out, tpw, row_stride), run_int<2>(src, dst, out, tpw, row_stride), run_int<3>(src, dst, out, tpw, row_stride));
+  {
+    run<3, true>(src, dst, out, tpw, 128, rows, row_stride);
+    float h[16];
+    hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    printf("split roles, both: cycles (s_memtime, 100 MHz) per wave of workgroup 7: mfma waves %.0f %.0f %.0f %.0f   stream waves %.0f %.0f %.0f %.0f\n",
+           h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+  }
   for (int mpt : {128}) {
     const float tm = run<1, true>(src, dst, out, tpw, mpt, rows, row_stride);
     const float ts = run<2, true>(src, dst, out, tpw, mpt, rows, row_stride);
