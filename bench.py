@@ -26,6 +26,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP runtime setting (not read by libfvp_hip.so): hardware queues per process.  With the default of 4, the compute streams
+# of the batches in flight, the result-gather stream and the default stream share queues; four batches in flight then
+# measured SLOWER than three (2 756 vs 2 938 frames/s), with >= 5 queues faster (3 016-3 020).  Must be set before the HIP
+# runtime initialises; an explicit value in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak
@@ -53,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary legs of the default line (other configs, B = 1 latency, long run, end to end)")
     ap.add_argument("--long-steps", type=int, default=300, help="steps of the secondary long run (value_long)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight: step i runs on HIP stream i %% S with its own scratch buffers, so the "
                          "detection stage of one batch overlaps the joint stage of the previous one")
     ap.add_argument("--prof-steps", type=int, default=5,

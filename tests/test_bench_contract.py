@@ -42,7 +42,7 @@ def test_committed_traffic_file_matches_the_headline_workload():
 
 def test_argument_surface():
     a = bench.parse_args([])
-    assert (a.gpus, a.batch, a.config, a.streams) == (1, 8, "panoptic", 3) and a.steps > 0 and a.warmup >= 0
+    assert (a.gpus, a.batch, a.config, a.streams) == (1, 8, "panoptic", 4) and a.steps > 0 and a.warmup >= 0
     a = bench.parse_args(["--gpus", "8", "--config", "panoptic128", "--batch", "1", "--steps", "5", "--warmup", "2"])
     assert (a.gpus, a.config, a.batch, a.steps, a.warmup) == (8, "panoptic128", 1, 5, 2)
     assert bench.parse_args(["--backbone"]).backbone

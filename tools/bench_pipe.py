@@ -4,6 +4,8 @@
 comes from bench.py with the product library."""
 import argparse
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # HIP runtime: see bench.py
 import sys
 import time
 
@@ -22,7 +24,7 @@ from faster_voxelpose_amd.models import faster_voxelpose as FV  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="panoptic")
 ap.add_argument("--batch", type=int, default=8)
-ap.add_argument("--streams", type=int, default=3)
+ap.add_argument("--streams", type=int, default=4)
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()

@@ -15,7 +15,7 @@ timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > "$out/pytest_
 cp "$out/parity_report.jsonl" "$dst/${tag}_parity_report.jsonl" 2>/dev/null
 echo "== bench"
 timeout 600 python bench.py --steps 20 --warmup 3 > "$dst/${tag}_bench_b8.json" 2> "$out/bench_${tag}.err"; echo "bench rc=$?"
-for spec in "1 1" "1 3" "2 3" "8 1" "8 2" "16 3" "32 3"; do
+for spec in "1 1" "1 4" "2 4" "8 1" "8 2" "8 3" "16 4" "32 4"; do
   set -- $spec
   timeout 300 python bench.py --steps 10 --warmup 3 --batch $1 --streams $2 --no-cpu-baseline --no-extra > "$dst/${tag}_bench_b$1_s$2.json" 2>> "$out/bench_${tag}.err"
 done
