@@ -1229,16 +1229,26 @@ static int launch_reg(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
 // weights fit LDS.  Returns -1 when the layer is not of that kind (the caller goes on to k_conv_dma).  The two kernels
 // produce the same bits, so the choice may depend on the amount of work: below reg_min_tiles() tiles (a few planes of
 // CenterNet's maps) the 256-pixel tiles of k_conv_dma spread over more CUs.
+static bool reg_shape_ok(const FvpConvOp& op, int planes, bool tr) {
+  const int hw = op.h * op.w;
+  if (kNoReg || op.cin != op.cinp || op.h <= 1 || hw % 32) return false;
+  if ((op.flags & FVP_EPI_RES) && op.cout % 8) return false;      // (residual rows are read through a uniform row pointer)
+  if (tr && (op.pair_off <= 0 || kNoPair)) return false;
+  return long(planes) * (hw / 32) >= reg_min_tiles(tr);
+}
+// the 64 -> 32 transposed conv with its fused 1x1 head runs on k_conv_reg (whose MFMA head takes up to 32 output channels;
+// k_conv_dma's fma-chain head stops at 16)
+static bool reg_takes_fused_head(const FvpConvOp& op, int planes) {
+  return op.kind == FVP_OP_CONVT2 && op.cinp == 64 && op.coutp == 32 && reg_shape_ok(op, planes, true);
+}
+
 static int plan_and_launch_reg(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s, bool tr) {
   const int hw = op.h * op.w;
-  if (kNoReg || op.cin != op.cinp || op.h <= 1 || hw % 32) return -1;
-  if ((op.flags & FVP_EPI_RES) && op.cout % 8) return -1;         // (residual rows are read through a uniform row pointer)
+  if (!reg_shape_ok(op, planes, tr)) return -1;
   const long tiles = long(planes) * (hw / 32);
-  if (tiles < reg_min_tiles(tr)) return -1;
   int mode = 0, NB = op.coutp / 32;
   a.wrow = op.coutp;
   if (tr) {
-    if (op.pair_off <= 0 || kNoPair) return -1;
     mode = a.w2 ? 2 : 1;
     NB = 2 * op.coutp / 32;
     a.wts = params + op.pair_off;
@@ -1540,7 +1550,7 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
           i + 1 < nops) {
         const FvpConvOp& nx = ops[i + 1];
         bool only = nx.kind == FVP_OP_CONV && nx.kh == 1 && nx.kw == 1 && nx.src == op.dst && nx.res < 0 && nx.cin == op.cout &&
-                    nx.cinp == 32 && nx.coutp == 32 && nx.cout <= 16 && nx.h == 2 * op.h && nx.w == 2 * op.w && nx.dst != op.dst &&
+                    nx.cinp == 32 && nx.coutp == 32 && (nx.cout <= 16 || reg_takes_fused_head(op, planes)) && nx.h == 2 * op.h && nx.w == 2 * op.w && nx.dst != op.dst &&
                     nx.dst >= 0 && nx.dst < nbufs;
         for (int j = i + 2; j < nops && only; ++j) only = ops[j].src != op.dst && ops[j].res != op.dst;
         if (only) head = &nx;

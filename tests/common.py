@@ -223,7 +223,7 @@ def split_k_stack(cin, cmid, hw, seed=0):
     return spec, w, ref, o
 
 
-def reg_stack(seed=0, fused_head=True):
+def reg_stack(seed=0, fused_head=True, head_cout=15):
     """1x1 convs and transposed convs with P2PNet's channel counts on 16x16 / 8x8 maps (whole 32-pixel tiles): the layers
     k_conv_reg takes.  x [planes, 32, 16, 16] -> 1x1 32->64, pool, 1x1 64->128, up 128->64 (+ skip), up 64->32 (+ skip),
     1x1 32->15 (fused into the second transposed conv when it is that conv's only consumer), 1x1 16->32 on a slice-free
@@ -236,7 +236,7 @@ def reg_stack(seed=0, fused_head=True):
     spec._conv_entries("t128", 64, 128, 1)
     spec._conv_entries("u64", 128, 64, 2, transposed=True)
     spec._conv_entries("u32", 64, 32, 2, transposed=True)
-    spec._conv_entries("head", 32, 15, 1)
+    spec._conv_entries("head", 32, head_cout, 1)
     spec._conv_entries("d16", 32, 16, 3)
     spec._conv_entries("s32", 16, 32, 1)
     s64 = spec.conv("s64", None, 0, 64, 1, relu=False)
@@ -244,7 +244,7 @@ def reg_stack(seed=0, fused_head=True):
     t128 = spec.conv("t128", None, p, 128, 1, relu=True)
     u64 = spec.up("u64", None, t128, 64, s64)
     u32 = spec.up("u32", None, p, 32, 0)
-    head = spec.conv("head", None, u32, 15, 1, relu=False)
+    head = spec.conv("head", None, u32, head_cout, 1, relu=False)
     d16 = spec.conv("d16", None, u32 if not fused_head else 0, 16, 3, relu=True)
     s32 = spec.conv("s32", None, d16, 32, 1, relu=False, res=0)
     spec.outputs.update(u64=u64, head=head, s32=s32)
@@ -256,7 +256,7 @@ def reg_stack(seed=0, fused_head=True):
         return {key + ".weight": torch.randn(shape, generator=g) / (cin * k * k) ** 0.5, key + ".bias": torch.randn(cout, generator=g) * 0.1}
     w = {}
     for args in (("s64", 64, 32, 1), ("t128", 128, 64, 1), ("u64", 64, 128, 2, True), ("u32", 32, 64, 2, True),
-                 ("head", 15, 32, 1), ("d16", 16, 32, 3), ("s32", 32, 16, 1)):
+                 ("head", head_cout, 32, 1), ("d16", 16, 32, 3), ("s32", 32, 16, 1)):
         w.update(wb(*args))
 
     def ref(x):

@@ -260,12 +260,12 @@ def test_split_k_direct_conv_on_small_maps(emu_lib, cin, cmid, hw, planes):
     np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("fused_head", [True, False])
-def test_register_direct_conv_equals_the_staged_kernel(emu_lib, monkeypatch, fused_head):
+@pytest.mark.parametrize("fused_head,head_cout", [(True, 15), (False, 15), (True, 17)])
+def test_register_direct_conv_equals_the_staged_kernel(emu_lib, monkeypatch, fused_head, head_cout):
     """k_conv_reg (1x1 convs, transposed convs, transposed conv + fused 1x1 head: activations straight from the map into
     MFMA operands, weights resident in LDS) against k_conv_dma on the same stack: the same bits (same ascending-channel
     MFMA chain), and both against a float64 torch evaluation.  Five planes: the last workgroup's waves run out of tiles."""
-    spec, w, ref, outs = reg_stack(seed=3, fused_head=fused_head)
+    spec, w, ref, outs = reg_stack(seed=3, fused_head=fused_head, head_cout=head_cout)   # 17: Shelf / Campus joints
     x = torch.from_numpy(np.random.default_rng(9).normal(size=(5, 32, 16, 16)).astype(np.float32))
     monkeypatch.setenv("FVP_CONV_REG_MIN_TILES", "1")
     got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)

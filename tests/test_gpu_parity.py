@@ -193,14 +193,14 @@ def test_split_k_direct_conv_on_small_maps(cin, cmid, hw, planes):
     assert torch.equal(one[0], got[planes - 1])
 
 
-@pytest.mark.parametrize("fused_head", [True, False])
-def test_register_direct_conv_is_batch_independent(fused_head):
+@pytest.mark.parametrize("fused_head,head_cout", [(True, 15), (False, 15), (True, 17)])
+def test_register_direct_conv_is_batch_independent(fused_head, head_cout):
     """1x1 convs / transposed convs (+ fused 1x1 head): 600 planes take k_conv_reg (>= 1024 tiles of 32 pixels on both map
     sizes), 3 planes take k_conv_dma - a plane's result must not depend on that (same MFMA chain: bit-identical), with a
     third of the planes masked out as well, and both match a float64 torch evaluation."""
     from faster_voxelpose_amd import _capi as capi
     lib = capi.load()
-    spec, w, ref, outs = reg_stack(seed=4, fused_head=fused_head)
+    spec, w, ref, outs = reg_stack(seed=4, fused_head=fused_head, head_cout=head_cout)
     x = torch.from_numpy(np.random.default_rng(6).normal(size=(600, 32, 16, 16)).astype(np.float32))
     st = torch.cuda.current_stream().cuda_stream
     big = run_custom_conv_stack(lib, DEV, spec, w, x, st)
