@@ -29,8 +29,10 @@ sys.path.insert(0, ROOT)
 # HIP runtime setting (not read by libfvp_hip.so): hardware queues per process.  With the default of 4, the compute streams
 # of the batches in flight, the result-gather stream and the default stream share queues; four batches in flight then
 # measured SLOWER than three (2 756 vs 2 938 frames/s), with >= 5 queues faster (3 016-3 020).  Must be set before the HIP
-# runtime initialises; an explicit value in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# runtime initialises; an explicit value in the environment wins.  8 is enough for ONE pipeline; this process builds five
+# (default line + Shelf / 128x128x32 / Campus / end-to-end legs, ~20 streams, never destroyed), and the later legs lost 5-10 %
+# on shared queues again (Shelf 2 512 vs 2 678): 24.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak

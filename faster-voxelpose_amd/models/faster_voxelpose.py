@@ -97,10 +97,14 @@ class PipelinedForward:
     ``event.wait()`` (or after ``synchronize()``).  Results are identical to the plain forward:
     every kernel is deterministic and replicas share nothing but read-only inputs."""
 
-    def __init__(self, model, depth=2):
+    def __init__(self, model, depth=2, streams=None):
+        """``streams``: optional list of >= depth ``torch.cuda.Stream`` to run on (a process that builds several pipelines
+        should hand them the same streams: the HIP runtime maps streams onto a fixed number of hardware queues -
+        GPU_MAX_HW_QUEUES, default 4 - and streams that share a queue serialise)."""
         assert depth >= 1
+        assert streams is None or len(streams) >= depth
         self.models = [model]
-        self.streams = [torch.cuda.Stream(device=model.device) for _ in range(depth)]
+        self.streams = list(streams[:depth]) if streams is not None else [torch.cuda.Stream(device=model.device) for _ in range(depth)]
         for _ in range(1, depth):
             m = FasterVoxelPoseNet(model.cfg).to(model.device)
             m.load_state_dict(model.state_dict())
