@@ -9,7 +9,7 @@ out="${here}/../libfvp_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 force="${FVP_BUILD_FORCE:-0}"
 [[ "${1:-}" == "--force" ]] && force=1
-srcs=(fvp_capi.hip fvp_project.hip fvp_conv.hip fvp_conv1d_fused.hip fvp_proposal.hip fvp_joint.hip fvp_heatmap.hip fvp_backbone.hip)
+srcs=(fvp_capi.hip fvp_project.hip fvp_conv.hip fvp_conv_wino.hip fvp_conv1d_fused.hip fvp_proposal.hip fvp_joint.hip fvp_heatmap.hip fvp_backbone.hip)
 hdrs=("${here}"/*.h "${here}/../../include/fvp.h")
 objs=()
 compiled=0
@@ -29,6 +29,9 @@ for s in "${srcs[@]}"; do
     # fvp_conv.hip: default contraction; its LDS-DMA inline asm writes M0 and says so in the clobber list, which hipcc
     # accepts with a warning per instantiation ("reserved register": 346 of them) - silenced, the clobber stays
     [[ "$s" == "fvp_conv.hip" ]] && extra=(-Wno-inline-asm)
+    # fvp_conv_wino.hip: additionally no SLP vectorisation - packed-f32 VALU (v_pk_add_f32) beside the fp32 MFMAs is an
+    # anti-lever on gfx950 (MI355X_MICROARCH.md); tests/test_kernel_resources.py checks the code object
+    [[ "$s" == "fvp_conv_wino.hip" ]] && extra=(-Wno-inline-asm -fno-slp-vectorize)
     # (a failed compile must not leave the previous object behind to be linked)
     ( "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" -c "${here}/$s" -o "$o.tmp" && mv "$o.tmp" "$o" || { rm -f "$o" "$o.tmp"; exit 1; } ) &
     pids+=($!)

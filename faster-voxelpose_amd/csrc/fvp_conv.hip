@@ -25,8 +25,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "fvp_asm.h"
-#include "fvp_common.h"
+#include "fvp_conv_args.h"
 
 // waves per SIMD the 1x1 / transposed-conv kernels are compiled for: they are HBM-bound, three waves (<= 168 VGPRs)
 // measured 11 us faster than two on the 64 -> 32 transposed conv, four spill
@@ -38,60 +37,6 @@ namespace fvp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kStageU = 4;   // independent 16-byte loads in flight per thread while staging
 constexpr int kStageS = 8;   // same for the 4-byte generic path
-
-// Division by a launch-constant: q = umulhi(x, magic), magic = floor(2^32/d) + 1 (exact for
-// 0 <= x < 2^32/d; d == 1 is flagged by magic == 0).  Runtime integer division costs ~40 VALU
-// instructions on gfx950; the index arithmetic of a workgroup used to contain ~90 of them.
-__device__ __forceinline__ int fdiv(int x, unsigned magic) { return magic ? int(__umulhi(unsigned(x), magic)) : x; }
-typedef fvp_i32x4 i32x4;
-
-static unsigned make_magic(int d) { return d <= 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; }
-
-// 1: k_conv_dma's chunk DMA uses buffer addressing (no vector instruction per item and chunk), 0: per-lane global addresses
-#ifndef FVP_CONV_BUF_DMA
-#define FVP_CONV_BUF_DMA 1
-#endif
-
-struct ConvArgs {
-  const float* src;
-  float* dst;
-  const float* res;
-  const float* wts;   // packed [cinp][KK][coutp] (+ tap-major blocks for transposed conv)
-  const float* epi;   // bias | scale | shift, each coutp
-  const uint8_t* plane_valid;
-  const float* zeros; // >= 16 bytes of zeros in device memory (head of the params blob)
-  int valid_div;
-  int planes, cin, cinp, cout, coutp;
-  int H, W;           // input spatial size
-  int OH, OW;         // output spatial size
-  int osy, osx;       // output stride (2 for transposed conv, else 1)
-  int TN, TH, TW;     // tile
-  int tiles_x, tiles_y;
-  int CC;             // input channels per LDS chunk (even)
-  int flags;
-  int ablate;         // diagnostics only (FVP_CONV_ABLATE): 1 skip input staging, 2 skip weight staging,
-                      // 4 skip the MFMA loop, 8 skip the epilogue stores
-  int dma;            // 1: k_conv_dma (pipelined LDS-DMA staging), needs vec
-  int vec;            // 1: full-width tile with W % 4 == 0 -> 16-byte staging, margin layout
-  int ntapT;          // 1, or number of transposed-conv taps (blockIdx.z)
-  int tapT_w;         // taps along x for the transposed conv (2), 1-D: 2, rows: ntapT / tapT_w
-  unsigned m_w, m_thw, m_qpr, m_rpc, m_thp;   // fdiv magics: TW, TH*TW, W/4, TN*(TH+KH-1), TH+KH-1
-  int tpp, tpr;       // Winograd: 2x2 tiles per plane band of a workgroup, tiles per row
-  int wino_ni;        // Winograd: input DMA rounds (of 512 x 16 B) per chunk
-  int nunits, ysplit; // Winograd: work units (plane group x row band x cout block), cout blocks
-  unsigned m_ys, m_ty; // fdiv magics: ysplit, tiles_y
-  unsigned long long* dbg;   // Winograd, diagnostics build (-DFVP_WINO_TIMING=1): phase cycle sums
-  float* pool_dst;    // Winograd: if set, max_pool(2,2) of the output is written here too (one value per 2x2 tile)
-  int wrow;           // k_conv_dma: floats per packed weight row (coutp, or 2*coutp for the paired transposed conv)
-  unsigned m_tpp, m_tpr;
-  // paired transposed conv with 32 couts: the 1x1 conv that consumes its output (P2PNet's output layer,
-  // cnns_2d.py:142) applied in the epilogue; the 32-channel map itself is then not stored
-  const float* w2;    // packed [32][coutp2 = 32] weights of that conv
-  const float* epi2;  // its bias | scale | shift
-  float* dst2;        // its output [planes][cout2][OH][OW]
-  int cout2, flags2;
-  int epi_off;        // k_conv_dma: float offset of the BN vectors' copy in dynamic LDS (behind slots and epilogue scratch)
-};
 
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue: bias, BN scale/shift, residual, ReLU; coalesced NCHW stores.  Residual values
@@ -900,7 +845,6 @@ __global__ void __launch_bounds__(256, (KH * KW == 1) ? FVP_CONV_1X1_OCC : 2) k_
 }
 
 }  // namespace fvp
-#include "fvp_conv_wino.h"
 #include "fvp_conv_reg.h"
 namespace fvp {
 
@@ -1025,19 +969,6 @@ static int dispatch_conv(int kh, int kw, int CB, int PB, const ConvArgs& a, dim3
   return FVP_ELIMIT;
 }
 
-// The LDS-DMA of k_conv_dma / k_conv_wino addresses a work unit's input and weights with 32-bit BYTE offsets against a
-// raw buffer descriptor whose num_records is 0x7ffffff0: per-lane offset (up to (TN + 1) planes of the plane group) plus
-// the scalar chunk offset (up to one plane).  An offset that wrapped or failed the range check would make the hardware
-// write zeros - a silently wrong result - so shapes outside the range are refused with FVP_ELIMIT here.
-static bool buf_dma_range_ok(int TN, int cin, int h, int w, double weight_floats) {
-  const double lim = double(0x7ffffff0u);
-  return (double(TN) + 2.0) * cin * h * w * 4.0 < lim && weight_floats * 4.0 < lim;
-}
-
-static size_t env_size(const char* name, size_t dflt) {
-  const char* v = fvp::diag_env(name);
-  return v ? size_t(atol(v)) : dflt;
-}
 // tuning knobs (diagnostics): FVP_CONV_LDS_KB, FVP_CONV_ABLATE, FVP_CONV_PB
 static const size_t kLdsBudget = env_size("FVP_CONV_LDS_KB", 64) * 1024;
 static const int kAblate = int(env_size("FVP_CONV_ABLATE", 0));
@@ -1054,162 +985,6 @@ static const int kNoReg = int(env_size("FVP_CONV_NO_REG", 0));     // diagnostic
 // B = 8: 16.3 -> 9.0 us at 400), 1x1 convs only from ~1 000 (64 -> 128 at 240 tiles: 7.4 -> 13.1 us).
 static long reg_min_tiles(bool transposed) { return long(env_size("FVP_CONV_REG_MIN_TILES", transposed ? 200 : 1024)); }
 static const int kNoKSplit = int(env_size("FVP_CONV_NO_KSPLIT", 0));   // diagnostics: no split-K form for the small-map 3x3 layers
-static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
-static const int kWinoGeneric = int(env_size("FVP_WINO_GENERIC", 0));
-static const int kWinoWC1 = int(env_size("FVP_WINO_WC1", 0));        // diagnostics: 32-cout blocks for every layer
-// 4-wave workgroups (32 couts x 64 tiles, <= 78 KB of LDS, two per CU) instead of one 8-wave workgroup per CU:
-// half-size work units.  Slower per FLOP when the launch has plenty of units (more LDS-DMA traffic per MFMA), but
-// a small batch (B = 1: 30 planes) has only 60-120 full-size units for 256 CUs.  FVP_WINO_HALF: 0 = automatic
-// (half-size units when the full-size ones cannot fill the CUs), 1 = always, 2 = never.  Both tilings perform the
-// same arithmetic in the same order, so the result does not depend on the choice (i.e. on the batch).
-static const int kWinoHalf = int(env_size("FVP_WINO_HALF", 0));
-static const int kWinoNoResW = int(env_size("FVP_WINO_NO_RESW", 0)); // diagnostics: stream the weights of the 32-channel layers too
-
-// Shapes the Winograd kernel covers: 3x3, even H, W a power of two in [8, 64*4] with W/2 dividing
-// a wave's 32 tiles or vice versa.  Decided from the layer SHAPE only (never from the number of
-// planes), so a frame's result does not depend on the batch it is computed in.
-static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int* TN, int* TR, bool half = false) {
-  if (h < 2 || (h & 1) || w < 8 || (w & 3) || (coutp != 32 && coutp % 64 != 0) || cinp % 4 != 0) return false;
-  // Maps whose rows do not divide the workgroup tile (CenterNet's 80x80 / 40x40 / 20x20 levels) are supported
-  // (masked tiles) but stay on the direct kernel by default: with a handful of planes the Winograd kernel is
-  // launch-latency bound just the same (measured 582 vs 564 us for CenterNet at B = 8), and the direct form is the
-  // exact fp32 fma chain, which keeps the detection map - the input of the bit-exact top-k - closest to the
-  // reference.  FVP_WINO_GENERIC=1 enables them (a SHAPE rule either way, never the batch).
-  if ((w & (w - 1)) && !kWinoGeneric) return false;
-  *WC = (coutp == 32 || kWinoWC1 || half) ? 1 : 2;
-  *WT = (half ? 4 : 8) / *WC;
-  // a unit = TN planes x TR tile rows x (w/2) tiles <= the workgroup's 16*WT tiles; tiles beyond that product
-  // (maps whose row length does not divide the workgroup tile: 80x80, 40x40, 20x20) are masked lanes
-  const int tpr = w / 2, TT = 16 * *WT, rows = h / 2;
-  if (tpr > TT) return false;
-  if (rows * tpr >= TT) {
-    *TN = 1;
-    *TR = TT / tpr;
-  } else {
-    *TN = TT / (rows * tpr);
-    *TR = rows;
-  }
-  return true;
-}
-
-template <int WC, int WT, int CC, bool RES, bool RESW = false>
-static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static LdsOptIn optin;
-  auto k = &k_conv_wino<WC, WT, CC, RES, RESW>;
-  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), 160 * 1024)) return e;
-  hipLaunchKernelGGL(k, grid, dim3(WC * WT * 64), lds, s, a);
-  return launch_status();
-}
-template <int WC, int WT>
-static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, bool resw) {
-  const bool res = a.flags & FVP_EPI_RES;
-  if (WC == 1 && WT == 8 && resw && a.CC == 8)
-    return res ? launch_wino2<1, 8, 8, true, true>(a, grid, lds, s) : launch_wino2<1, 8, 8, false, true>(a, grid, lds, s);
-  if (a.CC == 8) return res ? launch_wino2<WC, WT, 8, true>(a, grid, lds, s) : launch_wino2<WC, WT, 8, false>(a, grid, lds, s);
-  return res ? launch_wino2<WC, WT, 4, true>(a, grid, lds, s) : launch_wino2<WC, WT, 4, false>(a, grid, lds, s);
-}
-
-// one persistent 8-wave workgroup per CU
-static int persistent_workgroups() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    n = int(env_size("FVP_WINO_WGS", size_t(cus)));
-  }
-  return n;
-}
-
-static int plan_and_launch_wino(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
-  int WC, WT, TN, TR;
-  if (!wino_tiling(op.h, op.w, op.cinp, op.coutp, &WC, &WT, &TN, &TR, kWinoHalf == 1)) return FVP_EINVAL;
-  if (kWinoHalf == 0) {
-    // full-size units: (rows bands) x (plane groups) x (cout blocks); switch to half-size ones when they cannot fill the CUs
-    const long units = long(ceil_div(op.h / 2, TR)) * ceil_div(planes, TN) * (op.coutp / (32 * WC));
-    int wc, wt, tn, tr;
-    if (units < persistent_workgroups() && wino_tiling(op.h, op.w, op.cinp, op.coutp, &wc, &wt, &tn, &tr, true)) {
-      WC = wc; WT = wt; TN = tn; TR = tr;
-    }
-  }
-  a.wts = params + op.wino_off;
-  a.TN = TN;
-  a.TH = 2 * TR;
-  a.TW = op.w;
-  a.tiles_x = 1;
-  a.tiles_y = ceil_div(op.h / 2, TR);
-  a.tpp = TR * (op.w / 2);
-  a.m_tpp = make_magic(a.tpp);
-  a.tpr = op.w / 2;
-  a.m_tpr = make_magic(a.tpr);
-  a.vec = a.dma = 1;
-  a.zeros = params;
-  const int CBW = 32 * WC;
-  // channels per chunk: 8 when it divides cinp and three slots fit, else 4
-  // resident weights: one 32-cout block covers all couts and [cinp][32][16] fits beside the three input slots
-  const size_t resw_bytes = size_t(op.cinp) * CBW * 64;
-  const size_t budget = WC * WT == 4 ? std::min<size_t>(kWinoLdsBudget, 78 * 1024) : kWinoLdsBudget;   // two workgroups per CU
-  const size_t epi_bytes = size_t(3) * op.coutp * 4;     // bias | scale | shift in LDS
-  bool resw = WC == 1 && WT == 8 && op.coutp == 32 && op.cinp % 8 == 0 && resw_bytes <= 64 * 1024 && !kWinoNoResW;
-  auto slot_bytes = [&](int cc, int* ni, bool rw) {
-    const size_t quads = size_t(cc) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1;
-    const size_t per_round = size_t(WC) * WT * 64;       // one 16-byte item per thread and round
-    *ni = int((quads + per_round - 1) / per_round);
-    return size_t(*ni) * per_round * 16 + (rw ? 0 : size_t(cc) * CBW * 64);
-  };
-  int CC = op.cinp % 8 == 0 ? 8 : 4, ni = 0;
-  size_t slot = slot_bytes(CC, &ni, resw);
-  if (resw && (3 * slot + resw_bytes + 64 + epi_bytes > budget || ni > 4)) {
-    resw = false;
-    slot = slot_bytes(CC, &ni, false);
-  }
-  if (CC == 8 && !resw && (3 * slot + 64 + epi_bytes > budget || ni > 4)) {
-    CC = 4;
-    slot = slot_bytes(CC, &ni, false);
-  }
-  if (3 * slot + (resw ? resw_bytes : 0) + 64 + epi_bytes > budget || ni > 4) return FVP_ELIMIT;
-  a.CC = CC;
-  a.wino_ni = ni;
-  if (!buf_dma_range_ok(TN, op.cin, op.h, op.w, double(op.cinp) * op.coutp * 16)) return FVP_ELIMIT;
-  a.m_qpr = make_magic(op.w / 4 + 1);
-  a.m_rpc = make_magic(TN * (a.TH + 2));
-  a.m_thp = make_magic(a.TH + 2);
-  const size_t lds = 16 + 3 * slot + (resw ? resw_bytes : 0) + epi_bytes;
-  a.ysplit = op.coutp / CBW;
-  a.nunits = a.tiles_y * ceil_div(planes, TN) * a.ysplit;
-  a.m_ys = make_magic(a.ysplit);
-  a.m_ty = make_magic(a.tiles_y);
-  dim3 grid(std::min(a.nunits, persistent_workgroups() * (WC * WT == 4 ? 2 : 1)), 1, 1);
-  ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
-#if FVP_WINO_TIMING
-  static unsigned long long* dbg = nullptr;
-  if (!dbg && hipMalloc(&dbg, 32 * sizeof(unsigned long long)) != hipSuccess) dbg = nullptr;
-  if (dbg) (void)hipMemsetAsync(dbg, 0, 32 * sizeof(unsigned long long), s);
-  a.dbg = dbg;
-  int rc = (WC * WT == 4) ? launch_wino<1, 4>(a, grid, lds, s, false)
-                          : (WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false));
-  if (dbg && fvp::diag_env("FVP_WINO_TIMING_PRINT")) {
-    unsigned long long h[32];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-    static const char* nm[12] = {"lgkm wait", "fetch+transform", "mfma16(0)", "lgkm wait 2", "vm wait+barrier+fetch", "mfma16(1)", "loop gap", "kernel total", "vm wait", "barrier", "stage_next", "epilogue"};
-    fprintf(stderr, "[wino timing] %d->%d @%dx%d planes %d WC %d WT %d units %d grid %u\n", op.cin, op.cout, op.h, op.w, planes, WC, WT, a.nunits, grid.x);
-    for (int g = 0; g < 2; ++g) {
-      const unsigned long long* d = h + 16 * g;
-      if (!d[15]) continue;
-      fprintf(stderr, "   waves %s (%llu):", g ? "4-7" : "0-3", d[15]);
-      for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.0f |", nm[i], double(d[i]) / double(d[15]));
-      fprintf(stderr, "\n");
-    }
-  }
-  return rc;
-#else
-  if (WC * WT == 4) return launch_wino<1, 4>(a, grid, lds, s, false);
-  return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false);
-#endif
-}
-
 template <int K, int NB, int MODE>
 static int launch_reg(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static LdsOptIn optin[2];
@@ -1389,7 +1164,7 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   const int CBfull = op.coutp / 32;
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
   a.ablate = kAblate;
-  if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp) return plan_and_launch_wino(op, a, params, planes, s);
+  if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp) return wino_plan_and_launch(op, a, params, planes, s);
   // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
   // Large grids keep all couts in one workgroup (input tile staged once); small grids split
   // couts over blockIdx.y and shrink the pixel tile so that more CUs get work.
@@ -1587,8 +1362,7 @@ extern "C" int fvp_pack_conv(const float* weight, const float* bias, const float
   }
   if (op->wino_off > 0) {
     FVP_REQUIRE(!transposed && op->kh == 3 && op->kw == 3);
-    hipLaunchKernelGGL(k_pack_wino, dim3(ceil_div(op->cinp * op->coutp, 256)), dim3(256), 0, as_stream(s), weight,
-                       op->cin, op->cout, op->cinp, op->coutp, params + op->wino_off);
+    if (int rc = wino_pack(weight, *op, params, as_stream(s))) return rc;
   }
   return launch_status();
 }

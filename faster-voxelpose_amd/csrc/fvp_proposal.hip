@@ -158,6 +158,23 @@ k_proposals(const float* __restrict__ hm1d, const float* __restrict__ conf2d, co
   c[6] = match_bbox[size_t(i) * 2 + 1];
 }
 
+// ProposalLayer.forward on its own (human_detection_net.py:44-65, eval branch): same arithmetic as the tail of k_proposals
+__global__ void __launch_bounds__(64)
+k_proposal_layer(const long long* __restrict__ topk_index, const float* __restrict__ topk_confs,
+                 const float* __restrict__ match_bbox, const float* __restrict__ sb, float min_score, int BN,
+                 float* __restrict__ centers) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= BN) return;
+  const float conf = topk_confs[i];
+  float* c = centers + size_t(i) * 7;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) c[a] = __fadd_rn(__fmul_rn(float(topk_index[size_t(i) * 3 + a]), sb[a]), sb[3 + a]);
+  c[3] = (conf > min_score ? 1.0f : 0.0f) - 1.0f;
+  c[4] = conf;
+  c[5] = match_bbox[size_t(i) * 2];
+  c[6] = match_bbox[size_t(i) * 2 + 1];
+}
+
 }  // namespace fvp
 
 using namespace fvp;
@@ -202,5 +219,15 @@ extern "C" int fvp_proposals(const float* hm1d, const float* conf2d, const int64
   hipLaunchKernelGGL(k_proposals, dim3(ceil_div(B * N, 64)), dim3(64), 0, as_stream(s), hm1d, conf2d,
                      reinterpret_cast<const long long*>(idx2d), match_bbox, sb, min_score, B * N, Z,
                      reinterpret_cast<long long*>(topk_index), centers);
+  return launch_status();
+}
+
+extern "C" int fvp_proposal_layer(const int64_t* topk_index, const float* topk_confs, const float* match_bbox,
+                                  const float* sb, float min_score, int B, int N, float* centers, fvp_stream_t s) {
+  FVP_REQUIRE(topk_index && topk_confs && match_bbox && sb && centers && B >= 0 && N > 0);
+  if (B == 0) return 0;
+  ProfScope ps(FVP_K_OTHER, as_stream(s));
+  hipLaunchKernelGGL(k_proposal_layer, dim3(ceil_div(B * N, 64)), dim3(64), 0, as_stream(s),
+                     reinterpret_cast<const long long*>(topk_index), topk_confs, match_bbox, sb, min_score, B * N, centers);
   return launch_status();
 }

@@ -23,17 +23,33 @@ def _ptr(t):
 class SharedGeometry:
     """Per-sequence camera tables and the fine-grid coordinate cache of one device.  Read-only between (re)builds, so
     every replica of a ``PipelinedForward`` (one per batch in flight, each on its own HIP stream) uses ONE copy - each
-    replica used to build and re-read its own 164 MB cache (Panoptic).  ``ready`` is the completion event of the last
-    (re)build on the stream that issued it: users on other streams wait for it; superseded tensors are kept alive
-    (``retired``) because launches queued on other streams may still read them."""
+    replica used to build and re-read its own 164 MB cache (Panoptic).  ``pending`` holds the completion events of
+    EVERY (re)build not yet known to have finished, each recorded on the stream that issued it: a user on any stream
+    waits for all of them before it reads or extends the tables (two consecutive batches on different streams may each
+    introduce a new sequence: the second rebuild reads what the first is still writing).  Superseded tensors are kept
+    alive (``retired``) only until every stream that ever used the tables has passed the point of retirement."""
 
     def __init__(self):
         self.cams = None          # [nsets, V, 24]
         self.seq_ids = {}
         self.fine_grid = None     # [nsets, V, F0*F1*F2, 2]
         self.fine_grid_key = None
-        self.ready = None
-        self.retired = []
+        self.pending = []         # events of (re)builds that may still be running
+        self.users = {}           # stream handle -> torch stream: every stream that has read the tables
+        self.retired = []         # (tensor, [event per user stream at retirement])
+
+    def retire(self, tensor):
+        """Keep a superseded table alive until the launches already queued on every user stream have run."""
+        self.retired = [(t, evs) for t, evs in self.retired if not all(e.query() for e in evs)]
+        if tensor is None:
+            return
+        evs = []
+        for st in self.users.values():
+            e = torch.cuda.Event()
+            e.record(st)
+            evs.append(e)
+        if evs:
+            self.retired.append((tensor, evs))
 
 
 class HotPath:
@@ -177,20 +193,20 @@ class HotPath:
         geo = self.geo
         seqs = tuple(meta["seq"])
         new = [s for s in dict.fromkeys(seqs) if s not in geo.seq_ids]
+        self._await_geometry()                          # before reading OR extending geo.cams
         for s in new:
             assert s in cameras.keys(), "missing camera parameters for the current sequence"
             assert len(cameras[s]) == V, "inconsistent number of cameras"
             rows = np.stack([self._cam_row(cameras[s][c]) for c in range(V)])
             t = torch.from_numpy(rows).to(self.device)
-            if geo.cams is not None:
-                geo.retired.append(geo.cams)
+            geo.retire(geo.cams)
             geo.cams = t[None] if geo.cams is None else torch.cat([geo.cams, t[None]], dim=0)
             geo.seq_ids[s] = geo.cams.shape[0] - 1      # ids are append-only: other replicas' frame-set tensors stay valid
         if new:
             self._geometry_changed()
-        else:
-            self._await_geometry()
         if seqs not in self._frame_sets:
+            if len(self._frame_sets) >= 256:            # bounded: a long run over many sequence mixes
+                self._frame_sets.pop(next(iter(self._frame_sets)))
             self._frame_sets[seqs] = torch.tensor([geo.seq_ids[s] for s in seqs], dtype=torch.int32,
                                                   device=self.device)
         return self._frame_sets[seqs]
@@ -198,17 +214,22 @@ class HotPath:
     def _geometry_changed(self):
         """Mark the shared tables as (re)built by work queued on the current stream."""
         if self.device.type == "cuda":
-            self.geo.ready = torch.cuda.Event()
-            self.geo.ready.record(torch.cuda.current_stream(self.device))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.geo.pending.append(ev)
 
     def _await_geometry(self):
-        """Order the current stream behind the last (re)build of the shared tables (a no-op once it has completed)."""
-        ev = self.geo.ready
-        if ev is not None:
-            if ev.query():
-                self.geo.ready = None
-            else:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+        """Order the current stream behind EVERY (re)build of the shared tables that may still be running (a no-op once
+        they have completed) and register the stream as a user of the tables."""
+        if self.device.type != "cuda":
+            return
+        st = torch.cuda.current_stream(self.device)
+        geo = self.geo
+        geo.users.setdefault(st.cuda_stream, st)
+        if geo.pending:
+            geo.pending = [ev for ev in geo.pending if not ev.query()]
+            for ev in geo.pending:
+                st.wait_event(ev)
 
     def cams_of(self, seq):
         return self.geo.cams[self.geo.seq_ids[seq]]
@@ -223,14 +244,13 @@ class HotPath:
         n = self.fine[0] * self.fine[1] * self.fine[2]
         nsets = geo.cams.shape[0]
         if V * n * 8 > self.fine_grid_limit_bytes or nsets * V * n * 8 > self.fine_grid_total_limit_bytes:
-            if geo.fine_grid is not None:
-                geo.retired.append(geo.fine_grid)
+            geo.retire(geo.fine_grid)
             geo.fine_grid = None
             return None
         g = self.geom(resize_transform)
         key = (tuple(g.rt), g.clamp_max, V)
         if geo.fine_grid is not None and geo.fine_grid_key != key:
-            geo.retired.append(geo.fine_grid)
+            geo.retire(geo.fine_grid)
             geo.fine_grid = None                        # resize_transform changed: stale coordinates
         have = 0 if geo.fine_grid is None else geo.fine_grid.shape[0]
         if have < nsets:
@@ -239,7 +259,7 @@ class HotPath:
             new = torch.empty((nsets, V, n, 2), device=self.device)
             if have:
                 new[:have] = geo.fine_grid
-                geo.retired.append(geo.fine_grid)
+                geo.retire(geo.fine_grid)
             fa = self.fine_axes
             for i in range(have, nsets):
                 self._call("fvp_sample_grid", _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), self.fine[0], self.fine[1],
@@ -397,6 +417,18 @@ class HotPath:
         self.last = dict(cubes=cubes, zmax=zmax, conf2d=conf2d, idx2d=idx2d, flat=flat, topk_index=topk_index,
                          bbox_map=bbox_map, feat1d=feat1d, hm2d=hm2d, hm1d=hm1d, bbox_flat=bbox_flat)
         return hm2d, hm1d, centers, bbox_flat
+
+    def proposal_layer(self, topk_index, topk_confs, match_bbox, min_score):
+        """ProposalLayer.forward as a standalone launch (human_detection_net.py:44-65, eval branch)."""
+        self._check_tensor(topk_confs, "topk_confs")
+        self._check_tensor(match_bbox, "match_bbox_preds")
+        B, N = topk_confs.shape
+        idx = topk_index.to(torch.int64).contiguous()
+        assert idx.shape == (B, N, 3) and match_bbox.shape == (B, N, 2)
+        centers = torch.empty((B, N, 7), device=self.device)
+        self._call("fvp_proposal_layer", _ptr(idx), _ptr(topk_confs.contiguous()), _ptr(match_bbox.contiguous()),
+                   _ptr(self.prop_sb), float(min_score), B, N, _ptr(centers), self.stream())
+        return centers
 
     def person_frame(self, B, N):
         key = (B, N)

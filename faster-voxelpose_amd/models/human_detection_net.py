@@ -18,7 +18,9 @@ from .project_whole import ProjectLayer
 
 
 class ProposalLayer(nn.Module):
-    """Constants of the reference's ProposalLayer (:14-23); packing runs in ``fvp_proposals``."""
+    """Drop-in for the reference's ProposalLayer (:13-65, eval branch).  Inside ``HumanDetectionNet.forward`` the packing
+    is fused with the z arg-max (``fvp_proposals``); ``forward`` here is the same arithmetic as a standalone launch
+    (``fvp_proposal_layer``) for callers that use the layer on its own."""
 
     def __init__(self, cfg, _engine=None):
         super().__init__()
@@ -26,8 +28,16 @@ class ProposalLayer(nn.Module):
         self.min_score = cfg.CAPTURE_SPEC.MIN_SCORE
         self.device = torch.device(cfg.DEVICE)
         e = _engine
+        self.engine = e
         self.scale = e.prop_sb[0:3]
         self.bias = e.prop_sb[3:6]
+
+    def forward(self, topk_index, topk_confs, match_bbox_preds, meta):
+        """``topk_index`` [B,N,3] (voxel indices, any integer dtype), ``topk_confs`` [B,N], ``match_bbox_preds`` [B,N,2]
+        -> ``proposal_centers`` [B,N,7] (human_detection_net.py:44-65)."""
+        if self.training and ("roots_3d" in meta and "num_person" in meta):
+            raise NotImplementedError("training-time proposal matching is outside the inference hot path")
+        return self.engine.proposal_layer(topk_index, topk_confs, match_bbox_preds, self.min_score)
 
 
 class HumanDetectionNet(nn.Module):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FVP_ABI_VERSION 5
+#define FVP_ABI_VERSION 6
 #define FVP_MAX_VIEWS 8
 #define FVP_CAM_FLOATS 24 /* R[9] T[3] fx fy cx cy k[3] p[2] + 3 pad */
 #define FVP_MAX_JOINTS 32
@@ -221,6 +221,14 @@ int fvp_gather_proposals(const float* bbox_map, const float* cubes, const int64_
 int fvp_proposals(const float* hm1d, const float* conf2d, const int64_t* idx2d, const float* match_bbox,
                   const float* sb, float min_score, int B, int N, int Z, int64_t* topk_index, float* centers,
                   fvp_stream_t s);
+
+/* ---- a-11 standalone: ProposalLayer.forward, eval branch (human_detection_net.py:44-65) -----------
+ * topk_index [B][N][3] int64 (voxel indices x, y, z), topk_confs [B][N], match_bbox [B][N][2];
+ * centers [B][N][7] = (idx.float() * scale + bias as fp32 mul then add, no FMA), (conf > min_score) - 1,
+ * conf, bbox_w, bbox_h.  sb = scale[3], bias[3].  The forward path uses the fused fvp_proposals; this is
+ * the module-level drop-in for callers that invoke the layer on its own. */
+int fvp_proposal_layer(const int64_t* topk_index, const float* topk_confs, const float* match_bbox, const float* sb,
+                       float min_score, int B, int N, float* centers, fvp_stream_t s);
 
 /* ---- a-17/a-18 first half: soft-argmax + WeightNet per (person, plane, joint) map ----------------
  * feat [nP][3][J][C][C] (P2PNet output).  For each map: softmax(beta*x) over C*C cells,

@@ -310,6 +310,51 @@ def test_pipelined_forward_equals_plain_forward():
 
 
 @pytest.mark.gpu
+def test_pipelined_batches_each_introducing_a_new_sequence():
+    """Consecutive in-flight batches on different streams each bring a NEW sequence: the second rebuild of the shared
+    camera table / coordinate cache reads what the first is still writing on another stream (ADVICE round 4:
+    SharedGeometry kept only the LAST rebuild's event).  Every batch must equal the plain forward of a model that has
+    seen all sequences up front, and the superseded tables must be released once every stream has passed them."""
+    import copy
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = S.make_cfg("panoptic", device="cuda:0", min_score=-1.0)
+    cams, seq = S.load_cameras("panoptic")
+    rt = S.resize_transform(cfg).to("cuda:0")
+    cameras = {seq: cams[seq]}
+    names = [seq]
+    for i in range(1, 6):
+        c2 = copy.deepcopy(cams[seq])
+        for c in c2:
+            c["T"] = [[c["T"][0][0] + 60.0 * i], [c["T"][1][0] - 35.0 * i], [c["T"][2][0]]]
+        cameras[f"shift{i}"] = c2
+        names.append(f"shift{i}")
+    heats = [S.heatmaps_blobs(cfg, cams, seq, 2, people=3, seed=70 + i).to("cuda:0") for i in range(len(names))]
+    ref = FV.get(cfg).to("cuda:0")
+    sd = S.fill_state_dict(ref.state_dict(), seed=11)
+    ref.load_state_dict(sd)
+    model = FV.get(cfg).to("cuda:0")
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        want = []
+        for n, h in zip(names, heats):
+            f, p, c, _, _ = ref(meta={"seq": [n, names[0]]}, input_heatmaps=h, cameras=cameras, resize_transform=rt)
+            want.append((f.clone(), p.clone(), c.clone()))
+        torch.cuda.synchronize()
+        pipe = FV.PipelinedForward(model, depth=4)
+        got = [pipe.submit(meta={"seq": [n, names[0]]}, input_heatmaps=h, cameras=cameras, resize_transform=rt)
+               for n, h in zip(names, heats)]
+        pipe.synchronize()
+        torch.cuda.synchronize()
+    for (f, p, c), ((gf, gp, gc, _, _), ev) in zip(want, got):
+        assert ev.query()
+        assert torch.equal(f, gf) and torch.equal(p, gp) and torch.equal(c, gc)
+    geo = model.engine.geo
+    assert geo.cams.shape[0] == len(names) and geo.fine_grid.shape[0] == len(names)
+    geo.retire(None)                                 # everything has drained: nothing superseded stays alive
+    assert geo.retired == [] and len(geo.users) >= 2
+
+
+@pytest.mark.gpu
 def test_standalone_softargmax_and_weightnet_vs_oracle():
     """SoftArgmaxLayer.forward / WeightNet.forward as standalone launches (reference layout
     [3,P,J,C,C]) against the oracle's restatement of joint_localization_net.py:20-34 and

@@ -42,12 +42,17 @@ with torch.no_grad():
         pipe.submit(meta=meta, input_heatmaps=heats[i % 4], cameras=cams, resize_transform=rt)
     pipe.synchronize()
     rates = []
+    subs = []
     for r in range(a.reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
             pipe.submit(meta=meta, input_heatmaps=heats[i % 4], cameras=cams, resize_transform=rt)
+        t1 = time.perf_counter()
         pipe.synchronize()
         torch.cuda.synchronize()
-        rates.append(a.steps * a.batch / (time.perf_counter() - t0))
+        t2 = time.perf_counter()
+        rates.append(a.steps * a.batch / (t2 - t0))
+        subs.append((1e3 * (t1 - t0) / a.steps, 1e3 * (t2 - t1)))
+print(f"   host submit ms/step, drain ms: " + " ".join(f"{x:.3f}/{y:.2f}" for x, y in subs))
 print(f"{os.path.basename(capi.LIB_PATH)}: {a.config} B={a.batch} x{a.streams}: frames/s " + " ".join(f"{x:.0f}" for x in rates))
