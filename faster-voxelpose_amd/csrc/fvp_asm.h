@@ -34,6 +34,32 @@ __device__ __forceinline__ void asm_buffer_load_lds16(unsigned la, unsigned vo, 
                : "memory", "m0");
 }
 
+// ---- raw buffer addressing for ordinary loads / stores (k_conv_reg): descriptor in 4 SGPRs + ONE per-lane 32-bit byte
+// offset + a scalar byte offset per row.  "Uniform 64-bit row pointer + per-lane offset" - what round 4 wrote - costs an
+// SGPR PAIR per row in flight (64 rows at K = 128: the kernel spilled 143-628 SGPRs); here a row is one scalar add.
+// Range check (raw buffer, stride 0): a dword whose voffset + soffset + 4 exceeds num_records reads as 0 / is not written,
+// which replaces the `cout < a.cout` predicates of padded output rows.
+typedef __amdgpu_buffer_rsrc_t fvp_rsrc;
+__device__ __forceinline__ fvp_rsrc make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, int(bytes), 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(fvp_rsrc r, unsigned vo, unsigned so) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, int(vo), int(so), 0));
+}
+// (two dword loads: in this hipcc - ROCm 7.2 - __builtin_amdgcn_raw_buffer_load_b64 / _b96 / _b128 all lower to the i32
+// intrinsic and return element 0 in every lane of the result; found on the GPU, tools/micro/bufrange.hip prints it)
+__device__ __forceinline__ float2 buf_load_f32x2(fvp_rsrc r, unsigned vo, unsigned so) {
+  return make_float2(buf_load_f32(r, vo, so), buf_load_f32(r, vo + 4u, so));
+}
+__device__ __forceinline__ void buf_store_f32(float x, fvp_rsrc r, unsigned vo, unsigned so) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, int(vo), int(so), 0);
+}
+__device__ __forceinline__ void buf_store_f32x2(float2 x, fvp_rsrc r, unsigned vo, unsigned so) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 v = {__builtin_bit_cast(unsigned, x.x), __builtin_bit_cast(unsigned, x.y)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, int(vo), int(so), 0);
+}
+
 }  // namespace fvp
 
 #endif  // FVP_ASM_PRIMITIVES_PROVIDED

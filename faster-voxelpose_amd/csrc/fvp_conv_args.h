@@ -73,6 +73,22 @@ struct ConvArgs {
 };
 
 
+// Kernel arguments re-read at the point of use.  A by-value kernel argument is an invariant load from the kernarg
+// segment: hipcc hoists all of them to the top of the kernel and keeps ~60 SGPRs alive across the K loop (the spills of
+// round 4).  Behind an opaque copy of the segment pointer the loads stay where the source puts them.
+#if defined(HIPEMU)
+#define FVP_FRESH_ARGS(a) (&(a))
+typedef const ConvArgs* KArgsPtr;
+#else
+typedef const __attribute__((address_space(4))) ConvArgs* KArgsPtr;
+__device__ __forceinline__ KArgsPtr fresh_args_ptr() {
+  KArgsPtr p = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#define FVP_FRESH_ARGS(a) fresh_args_ptr()
+#endif
+
 // The LDS-DMA of k_conv_dma / k_conv_wino addresses a work unit's input and weights with 32-bit BYTE offsets against a
 // raw buffer descriptor whose num_records is 0x7ffffff0: per-lane offset (up to (TN + 1) planes of the plane group) plus
 // the scalar chunk offset (up to one plane).  An offset that wrapped or failed the range check would make the hardware

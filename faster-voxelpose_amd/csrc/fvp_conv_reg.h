@@ -59,23 +59,28 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? FVP_REG_OCC_SMALL : 2)) 
   const int ntiles = a.planes * tpp;
   const int stride = gridDim.x * 4;
 
-  // tiles of masked planes are skipped (k_conv_dma: whole workgroups return)
+  // tiles of masked planes are skipped (k_conv_dma: whole workgroups return); the tile index stays wave-uniform for the
+  // compiler too (the flag comes back from a vector load), or every descriptor below would be built in a waterfall loop
   auto next_valid = [&](int tl) {
     if (a.plane_valid)
-      while (tl < ntiles && !a.plane_valid[fdiv(tl, a.m_tpp) / a.valid_div]) tl += stride;
-    return tl;
+      while (tl < ntiles && !__builtin_amdgcn_readfirstlane(int(a.plane_valid[fdiv(fdiv(tl, a.m_tpp), a.m_vd)]))) tl += stride;
+    return __builtin_amdgcn_readfirstlane(tl);
   };
-  // every global access of the loop is "uniform row pointer + one per-lane 32-bit offset" (scalar base, one offset
-  // register for all K / 2 loads resp. all rows of the tile): 64-bit per-lane addresses cost two registers per load in flight
-  const unsigned voff_in = unsigned(half * HW + l31);
+  // Every global access of the loop is raw-buffer addressed (round 5): descriptor of the tile's first row (4 SGPRs), ONE
+  // per-lane byte offset for all K / 2 loads resp. all rows of the tile, one scalar byte offset per row (a multiple of the
+  // row stride, recomputed where it is used: FVP_OPAQUE keeps hipcc from hoisting 64 of them out of the tile loop).
+  // Round 4 had a 64-bit scalar pointer per row: an SGPR pair per row in flight, 143-628 SGPR spills per instance.
+  const unsigned voff_in = unsigned(half * HW + l31) * 4u;
   float b[K / 2];
 #pragma unroll
   for (int s = 0; s < K / 2; ++s) b[s] = 0.0f;           // (only read un-loaded under the diagnostics ablation)
   auto load_b = [&](int tl) {
     const int pl = fdiv(tl, a.m_tpp);
-    const float* sp = a.src + size_t(pl) * K * HW + (tl - pl * tpp) * 32;
+    const fvp_rsrc rs = make_rsrc(a.src + size_t(pl) * K * HW + (tl - pl * tpp) * 32, 0x7ffffff0u);
+    unsigned hw8 = unsigned(HW) * 8u;                   // two channels further
+    FVP_OPAQUE(hw8);
 #pragma unroll
-    for (int s = 0; s < K / 2; ++s) b[s] = (sp + size_t(2 * s) * HW)[voff_in];
+    for (int s = 0; s < K / 2; ++s) b[s] = buf_load_f32(rs, voff_in, unsigned(s) * hw8);
   };
   // the first tile's operands are on their way while the weights are staged
   int tile = next_valid(blockIdx.x * 4 + wave);
@@ -121,26 +126,31 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? FVP_REG_OCC_SMALL : 2)) 
   while (tile < ntiles) {
     const int plane = fdiv(tile, a.m_tpp);
     const int px = (tile - plane * tpp) * 32 + l31;
-    // per-lane part of an output address: the pixel, and 4 rows further for the upper half wave; row (r, nb) adds a uniform
-    // (nb * 32 + (r & 3) + 8 (r >> 2)) * ostep.  (host: cout % 8 == 0 when there is a residual, so a clamped row + 4 stays inside)
-    unsigned ostep, voff;
+    // per-lane part of an output address (bytes): the pixel, and 4 rows further for the upper half wave; row (r, nb) adds
+    // the scalar (nb * 32 + (r & 3) + 8 (r >> 2)) * ostep4.  The output / residual descriptors start at cout co0 of the
+    // plane and end behind its last cout: padded rows fail the range check (loads return 0, stores are dropped).
+    unsigned ostep4, voff;
     if (MODE == 0) {
-      ostep = unsigned(HW);
-      voff = unsigned(px) + 4u * unsigned(half) * ostep;
+      ostep4 = unsigned(HW) * 4u;
+      voff = unsigned(px) * 4u + 4u * unsigned(half) * ostep4;
     } else {
       const int y = fdiv(px, a.m_w), x = px - y * W;
-      ostep = unsigned(OHW);
-      voff = unsigned((2 * y + dy) * a.OW + 2 * x) + 4u * unsigned(half) * ostep;
+      ostep4 = unsigned(OHW) * 4u;
+      voff = unsigned((2 * y + dy) * a.OW + 2 * x) * 4u + 4u * unsigned(half) * ostep4;
     }
-    const size_t pbase = size_t(plane) * a.cout * ostep;
+    FVP_OPAQUE(ostep4);
+    const size_t pbase = (size_t(plane) * a.cout + co0) * (ostep4 >> 2);
+    const unsigned obytes = a.cout > co0 ? unsigned(a.cout - co0) * ostep4 : 0u;
+    const fvp_rsrc rd = make_rsrc(a.dst + pbase, obytes);
     typedef typename std::conditional<MODE == 0, float, float2>::type res_t;
     res_t rv[PFR ? NR : 1][16];
     auto load_res = [&](int nb, res_t (&dst)[16]) {
+      const fvp_rsrc rr = make_rsrc(a.res + pbase, obytes);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int cu = co0 + nb * 32 + (r & 3) + 8 * (r >> 2);
-        const float* rowp = a.res + pbase + size_t(cu < a.cout ? cu : 0) * ostep;
-        dst[r] = *reinterpret_cast<const res_t*>(rowp + voff);
+        const unsigned so = unsigned(nb * 32 + (r & 3) + 8 * (r >> 2)) * ostep4;
+        if constexpr (MODE == 0) dst[r] = buf_load_f32(rr, voff, so);
+        else dst[r] = buf_load_f32x2(rr, voff, so);
       }
     };
     if (PFR) {
@@ -197,7 +207,7 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? FVP_REG_OCC_SMALL : 2)) 
           if (HAS_RES && !res_after) v += rr;
           if (relu) v = fmaxf(v, 0.0f);
           if (HAS_RES && res_after) v += rr;
-          if (co < a.cout) (a.dst + pbase + size_t(co - 4 * half) * ostep)[voff] = v;
+          buf_store_f32(v, rd, voff, unsigned(nb * 32 + (r & 3) + 8 * (r >> 2)) * ostep4);
         }
       }
     } else {
@@ -223,8 +233,8 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? FVP_REG_OCC_SMALL : 2)) 
           if (MODE == 2) {
             acc[cb][r] = v[0];                         // B operands of the fused 1x1 conv
             acc[cb + CH][r] = v[1];
-          } else if (co < a.cout) {
-            *reinterpret_cast<float2*>(a.dst + pbase + size_t(co - 4 * half) * ostep + voff) = make_float2(v[0], v[1]);
+          } else {
+            buf_store_f32x2(make_float2(v[0], v[1]), rd, voff, unsigned(cb * 32 + (r & 3) + 8 * (r >> 2)) * ostep4);
           }
         }
       }
@@ -257,7 +267,7 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? FVP_REG_OCC_SMALL : 2)) 
         const float* scale2 = epi2_s + 32;
         const float* shift2 = epi2_s + 64;
         const bool relu2 = a.flags2 & FVP_EPI_RELU;
-        const size_t pbase2 = size_t(plane) * a.cout2 * ostep;
+        const fvp_rsrc rd2 = make_rsrc(a.dst2 + size_t(plane) * a.cout2 * (ostep4 >> 2), unsigned(a.cout2) * ostep4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -266,7 +276,7 @@ __global__ void __launch_bounds__(256, (K * NB <= 128 ? FVP_REG_OCC_SMALL : 2)) 
             x0 = fmaxf(x0, 0.0f);
             x1 = fmaxf(x1, 0.0f);
           }
-          if (j < a.cout2) *reinterpret_cast<float2*>(a.dst2 + pbase2 + size_t(j - 4 * half) * ostep + voff) = make_float2(x0, x1);
+          buf_store_f32x2(make_float2(x0, x1), rd2, voff, unsigned((r & 3) + 8 * (r >> 2)) * ostep4);
         }
       }
     }

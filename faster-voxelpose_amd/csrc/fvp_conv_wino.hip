@@ -49,22 +49,6 @@ namespace fvp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Kernel arguments re-read at the point of use.  A by-value kernel argument is an invariant load from the kernarg
-// segment: hipcc hoists all of them to the top of the kernel and keeps ~60 SGPRs alive across the K loop (the spills of
-// round 4).  Behind an opaque copy of the segment pointer the loads stay where the source puts them.
-#if defined(HIPEMU)
-#define FVP_FRESH_ARGS(a) (&(a))
-typedef const ConvArgs* KArgsPtr;
-#else
-typedef const __attribute__((address_space(4))) ConvArgs* KArgsPtr;
-__device__ __forceinline__ KArgsPtr fresh_args_ptr() {
-  KArgsPtr p = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
-  return p;
-}
-#define FVP_FRESH_ARGS(a) fresh_args_ptr()
-#endif
-
 // s_waitcnt vmcnt(N) with an immediate (lgkmcnt / expcnt untouched)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_imm() {

@@ -235,6 +235,29 @@ static inline void asm_buffer_load_lds16(unsigned la, unsigned vo, const fvp_i32
     memcpy(dst + 4 * d, &v, 4);
   }
 }
+// raw buffer loads / stores (k_conv_reg): dword-granular range check against num_records, scalar offset included
+struct fvp_rsrc {
+  char* base;
+  unsigned long long nrec;
+};
+static inline fvp_rsrc make_rsrc(const void* p, unsigned bytes) { return fvp_rsrc{(char*)p, bytes}; }
+static inline float buf_load_f32(fvp_rsrc r, unsigned vo, unsigned so) {
+  const unsigned long long off = (unsigned long long)vo + so;
+  float v = 0.0f;
+  if (off + 4 <= r.nrec) memcpy(&v, r.base + off, 4);
+  return v;
+}
+static inline float2 buf_load_f32x2(fvp_rsrc r, unsigned vo, unsigned so) {
+  return make_float2(buf_load_f32(r, vo, so), buf_load_f32(r, vo + 4, so));
+}
+static inline void buf_store_f32(float x, fvp_rsrc r, unsigned vo, unsigned so) {
+  const unsigned long long off = (unsigned long long)vo + so;
+  if (off + 4 <= r.nrec) memcpy(r.base + off, &x, 4);
+}
+static inline void buf_store_f32x2(float2 x, fvp_rsrc r, unsigned vo, unsigned so) {
+  buf_store_f32(x.x, r, vo, so);
+  buf_store_f32(x.y, r, vo + 4, so);
+}
 }  // namespace fvp
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
