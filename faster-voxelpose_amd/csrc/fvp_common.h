@@ -8,6 +8,9 @@
 // motion from hoisting dozens of derived LDS addresses out of a hot loop into live registers).
 #ifndef FVP_OPAQUE
 #define FVP_OPAQUE(x) asm volatile("" : "+s"(x))
+// two wave-uniform values made opaque together, optionally ordered after the computation of a vector value
+#define FVP_OPAQUE_PAIR(s0, s1) asm volatile("" : "+s"(s0), "+s"(s1))
+#define FVP_OPAQUE_PAIR_AFTER(s0, s1, vdep) asm volatile("" : "+s"(s0), "+s"(s1) : "v"(vdep))
 #endif
 
 // The shipped library reads NO environment variable.  Every kernel-selection, tuning and ablation switch documented in

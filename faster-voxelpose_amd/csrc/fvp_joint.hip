@@ -94,6 +94,11 @@ k_softargmax_weightnet(const float* __restrict__ feat, const float* __restrict__
   float sum[kMaxF];
 #pragma unroll
   for (int f = 0; f < kMaxF; ++f) sum[f] = 0.0f;
+  // (Round 5 tried to get rid of this loop's 24 SGPR spills - 32 `f < F` predicates kept as SGPR pairs plus 12 F hoisted
+  // scalars: a template on F == kMaxF without the predicates spills 787 SGPRs (hipcc then hoists every scalar); re-reading
+  // the scalars behind an opaque table pointer per window or per feature group, ordered after an earlier feature's result,
+  // compiles to 0 spills but measured 252-299 us against 177 us and was not bit-stable with several batches in flight.
+  // The spills are the cheaper form: tests/test_kernel_resources.py records the count.)
   for (int w = t; w < NWIN; w += 256) {
     const int wy = w / PW, wx = w - wy * PW;
     float patch[4][4];                             // rows 2wy-1 .. 2wy+2, cols 2wx-1 .. 2wx+2

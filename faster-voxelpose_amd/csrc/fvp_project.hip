@@ -168,7 +168,9 @@ k_project_individual(const float* __restrict__ heat_cl, const Cam* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // Orthographic maxima of a materialised cube: one workgroup per (person, joint), x-slabs
-// streamed through LDS; yz keeps a running max in registers.
+// streamed through LDS; yz keeps a running max in registers.  PER = (y,z) cells per thread, a power of two >= C*C/256
+// (as a run-time bound on a 64-deep unrolled loop the 64 `i < per` predicates were kept as SGPR pairs: 78 spills, round 4).
+template <int PER>
 __global__ void __launch_bounds__(256)
 k_triplane_max(const float* __restrict__ cubes, float* __restrict__ planes, int J, int C) {
   HIP_DYNAMIC_SHARED(float, slab)                     // [C][C+1]
@@ -178,21 +180,20 @@ k_triplane_max(const float* __restrict__ cubes, float* __restrict__ planes, int 
   float* pxy = planes + ((size_t(p) * 3 + 0) * J + j) * CC;
   float* pxz = planes + ((size_t(p) * 3 + 1) * J + j) * CC;
   float* pyz = planes + ((size_t(p) * 3 + 2) * J + j) * CC;
-  const int per = (CC + 255) / 256;                   // (y,z) cells per thread, <= 64 for C <= 128
-  float run[64];
+  float run[PER];
 #pragma unroll
-  for (int i = 0; i < 64; ++i) run[i] = -INFINITY;
+  for (int i = 0; i < PER; ++i) run[i] = -INFINITY;
   for (int x = 0; x < C; ++x) {
     __syncthreads();
+    int ncell = CC;
+    FVP_OPAQUE(ncell);                                // (the PER bounds tests stay in the loop: hoisted, each is an SGPR pair)
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      if (i < per) {
-        const int cell = t + i * 256;
-        if (cell < CC) {
-          const float v = cube[size_t(x) * CC + cell];
-          slab[(cell / C) * ld + (cell % C)] = v;
-          run[i] = fmaxf(run[i], v);
-        }
+    for (int i = 0; i < PER; ++i) {
+      const int cell = t + i * 256;
+      if (cell < ncell) {
+        const float v = cube[size_t(x) * CC + cell];
+        slab[(cell / C) * ld + (cell % C)] = v;
+        run[i] = fmaxf(run[i], v);
       }
     }
     __syncthreads();
@@ -210,11 +211,9 @@ k_triplane_max(const float* __restrict__ cubes, float* __restrict__ planes, int 
     }
   }
 #pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    if (i < per) {
-      const int cell = t + i * 256;
-      if (cell < CC) pyz[cell] = run[i];
-    }
+  for (int i = 0; i < PER; ++i) {
+    const int cell = t + i * 256;
+    if (cell < CC) pyz[cell] = run[i];
   }
 }
 
@@ -777,8 +776,15 @@ extern "C" int fvp_triplane_max(const float* cubes, float* planes, int nP, int J
   FVP_LIMIT(C <= 128);
   if (nP == 0) return 0;
   ProfScope ps(FVP_K_OTHER, as_stream(s));
-  hipLaunchKernelGGL(k_triplane_max, dim3(J, nP), dim3(256), size_t(C) * (C + 1) * sizeof(float), as_stream(s), cubes,
-                     planes, J, C);
+  const int per = (C * C + 255) / 256;                 // <= 64 for C <= 128
+  const dim3 grid(J, nP);
+  const size_t lds = size_t(C) * (C + 1) * sizeof(float);
+#define FVP_TRIMAX(PER_) hipLaunchKernelGGL(k_triplane_max<PER_>, grid, dim3(256), lds, as_stream(s), cubes, planes, J, C)
+  if (per <= 1) FVP_TRIMAX(1);
+  else if (per <= 4) FVP_TRIMAX(4);
+  else if (per <= 16) FVP_TRIMAX(16);
+  else FVP_TRIMAX(64);
+#undef FVP_TRIMAX
   return launch_status();
 }
 

@@ -26,6 +26,8 @@
 
 #define HIPEMU 1
 #define FVP_OPAQUE(x) ((void)0)
+#define FVP_OPAQUE_PAIR(s0, s1) ((void)0)
+#define FVP_OPAQUE_PAIR_AFTER(s0, s1, vdep) ((void)0)
 #define __global__
 #define __device__
 #define __host__

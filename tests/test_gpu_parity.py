@@ -310,6 +310,34 @@ def test_pipelined_forward_equals_plain_forward():
 
 
 @pytest.mark.gpu
+def test_pipelined_single_frame_batches_are_bit_stable_under_concurrency():
+    """B = 1 (half-size Winograd units, two workgroups per CU; direct kernels instead of the register-direct ones), four
+    batches in flight, 40 batches: every result equals the serial forward bit for bit.  Kernels from other streams share
+    the CUs here, which is where a timing-dependent hazard shows (round 5: a soft-argmax variant that was bit-exact alone
+    differed in 1 of 4 batches under this load)."""
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = S.make_cfg("panoptic", device="cuda:0", min_score=-1.0)
+    cams, seq = S.load_cameras("panoptic")
+    rt = S.resize_transform(cfg).to("cuda:0")
+    model = FV.get(cfg).to("cuda:0")
+    model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=13))
+    heats = [S.heatmaps_blobs(cfg, cams, seq, 1, people=4, seed=90 + i).to("cuda:0") for i in range(4)]
+    meta = {"seq": [seq]}
+    with torch.no_grad():
+        want = []
+        for h in heats:
+            f, p, c, _, _ = model(meta=meta, input_heatmaps=h, cameras=cams, resize_transform=rt)
+            want.append((f.clone(), p.clone(), c.clone()))
+        torch.cuda.synchronize()
+        pipe = FV.PipelinedForward(model, depth=4)
+        got = [pipe.submit(meta=meta, input_heatmaps=heats[i % 4], cameras=cams, resize_transform=rt) for i in range(40)]
+        pipe.synchronize()
+    bad = [i for i, ((gf, gp, gc, _, _), _) in enumerate(got)
+           if not (torch.equal(want[i % 4][0], gf) and torch.equal(want[i % 4][1], gp) and torch.equal(want[i % 4][2], gc))]
+    assert not bad, f"batches that differ from the serial forward: {bad}"
+
+
+@pytest.mark.gpu
 def test_pipelined_batches_each_introducing_a_new_sequence():
     """Consecutive in-flight batches on different streams each bring a NEW sequence: the second rebuild of the shared
     camera table / coordinate cache reads what the first is still writing on another stream (ADVICE round 4:

@@ -14,7 +14,7 @@ objs=()
 for s in fvp_capi fvp_project fvp_conv fvp_conv_wino fvp_conv1d_fused fvp_proposal fvp_joint fvp_heatmap fvp_backbone; do
   o="$out/obj_$name/$s.o"
   extra=(-ffp-contract=off); [[ "$s" == "fvp_conv" ]] && extra=(-Wno-inline-asm); [[ "$s" == "fvp_conv_wino" ]] && extra=(-Wno-inline-asm -fno-slp-vectorize)
-  if [[ "$s" == "fvp_capi" || "$s" == "fvp_conv" || "$s" == "fvp_conv_wino" || "$s" == "fvp_conv1d_fused" || "$s" == "fvp_project" || "$s" == "fvp_backbone" || ! -f "$csrc/$s.o" ]]; then
+  if [[ "$s" == "fvp_capi" || "$s" == "fvp_conv" || "$s" == "fvp_conv_wino" || "$s" == "fvp_conv1d_fused" || "$s" == "fvp_joint" || "$s" == "fvp_project" || "$s" == "fvp_backbone" || ! -f "$csrc/$s.o" ]]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DFVP_DIAG=1 "${extra[@]}" "$@" -c "$csrc/$s.hip" -o "$o" &
   else
     cp "$csrc/$s.o" "$o"
