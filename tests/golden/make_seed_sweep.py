@@ -29,7 +29,7 @@ import seed_sweep as SW  # noqa: E402
 def run(ref, name):
     fused32, fused64, centers_all, valid_all = [], [], [], []
     model = orc = None
-    for seed in SW.SEEDS:
+    for seed in SW.seeds_of(name):
         t0 = time.time()
         cfg, cams, seq, rt, heat, meta, _ = SW.make_inputs(name, seed)
         if model is None:
@@ -54,7 +54,7 @@ def run(ref, name):
               f"median {float(d.median()) if d.numel() else 0:.2e}  joints with floor <= 4e-4: {int((d <= SW.FLOOR_OK).sum())}/{d.numel()}  "
               f"min |conf - thr| {float((conf - SW.MIN_SCORE).abs().min()) if conf.numel() else 0:.3f}  ({time.time() - t0:.0f} s)", flush=True)
     np.savez_compressed(SW.path(name), fused32=np.stack(fused32), fused64=np.stack(fused64), centers=np.stack(centers_all),
-                        valid=np.stack(valid_all), seeds=np.array(SW.SEEDS, np.int64), min_score=np.float64(SW.MIN_SCORE))
+                        valid=np.stack(valid_all), seeds=np.array(SW.seeds_of(name), np.int64), min_score=np.float64(SW.MIN_SCORE))
     print(f"   -> {os.path.relpath(SW.path(name), ROOT)}  {os.path.getsize(SW.path(name)) / 1024:.0f} KiB", flush=True)
 
 

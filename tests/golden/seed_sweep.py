@@ -65,13 +65,21 @@ SWEEPS = {
     "shelf_b2": ("shelf", 2, [5, 4], 11),
     "panoptic128_b1": ("panoptic128", 1, [5], 7),                      # BASELINE configs[3]: 128x128x32, jln128
     "campus_b2": ("campus", 2, [3, 3], 7),
+    # round 5: the largest batch bench.py reports a rate for (B = 32), three seeds = 96 frames (the B = 8 sweep has 80)
+    "panoptic_b32": ("panoptic", 32, [6, 5, 4, 6, 5, 4, 6, 5] * 4, 7, [1, 2, 3]),
 }
+
+
+def seeds_of(name):
+    """Heatmap seeds of a sweep: SEEDS unless the entry carries its own list."""
+    e = SWEEPS[name]
+    return list(e[4]) if len(e) > 4 else list(SEEDS)
 
 
 def make_inputs(name, seed, device="cpu"):
     import fvp_synthetic as S
     from cases import CONDITIONED
-    shape, B, people, wseed = SWEEPS[name]
+    shape, B, people, wseed = SWEEPS[name][:4]
     cfg = S.make_cfg(shape, device=device, min_score=MIN_SCORE)
     cams, seq = S.load_cameras(shape)
     rt = S.resize_transform(cfg)
@@ -116,6 +124,17 @@ def compare(name, seed_index, fused, g):
 
 
 def summarise(errs, floors, bars, pfloors):
+    # per PROPOSAL (round 5): worst joint error over the proposal's own reference floor - the predicate of
+    # tests/common.py::FLOOR_RULE (bar 2.0 on the hand-picked Campus fixture) evaluated on every compared proposal of
+    # every seed.  errs[i] / pfloors[i] are [n_proposals, J] per seed.
+    pr = [e.max(axis=1) / np.maximum(pf[:, 0], 1e-30) for e, pf in zip(errs, pfloors) if e.ndim == 2 and e.size]
+    pr = np.concatenate(pr) if pr else np.zeros(0)
+    pstats = {"proposals": int(pr.size),
+              "proposals_within_2x_own_floor": int((pr <= 2.0).sum()),
+              "proposals_within_1.5x_own_floor": int((pr <= 1.5).sum()),
+              "worst_proposal_err_over_own_floor": float(pr.max()) if pr.size else 0.0,
+              "median_proposal_err_over_own_floor": float(np.median(pr)) if pr.size else 0.0}
+    errs, floors, bars, pfloors = ([a.reshape(-1) for a in x] for x in (errs, floors, bars, pfloors))
     err, floor, bar, pfloor = (np.concatenate(a) if len(a) else np.zeros(0) for a in (errs, floors, bars, pfloors))
     low = floor <= FLOOR_OK
     plow = pfloor <= FLOOR_OK
@@ -132,7 +151,8 @@ def summarise(errs, floors, bars, pfloors):
             "joints_r1q": int(q.sum()), "max_mm_r1q": float(err[q].max()) if q.any() else 0.0,
             "violations_r1q": int((err[q] > bar[q]).sum()),
             "reference_floor_max_mm": float(floor.max()) if floor.size else 0.0,
-            "worst_err_over_proposal_floor": float((err / np.maximum(pfloor, FLOOR_OK)).max()) if err.size else 0.0}
+            "worst_err_over_proposal_floor": float((err / np.maximum(pfloor, FLOOR_OK)).max()) if err.size else 0.0,
+            **pstats}
 
 
 def replay(name, dev, seeds=None, detail_path=None):

@@ -56,7 +56,32 @@ def test_golden_case(case):
         print(report)
 
 
-@pytest.mark.parametrize("name", ["panoptic_b8", "shelf_b2", "panoptic128_b1", "campus_b2"])
+@pytest.mark.parametrize("case", ["panoptic_g_b2_thr", "campus_u_b2_all", "shelf_c_b1_thr"])
+def test_proposal_layer_forward_standalone(case):
+    """ProposalLayer.forward (human_detection_net.py:44-65, eval branch) called on its own, like the reference's module:
+    fed with the reference's topk_index / topk_confs / match_bbox_preds it returns the reference's proposal_centers bit
+    for bit (idx * scale + bias without fma, (conf > MIN_SCORE) - 1, pass-through columns); integer dtypes other than
+    int64 are accepted; the training branch refuses."""
+    cfg, cams, seq, rt, heat, meta, wseed = make_inputs(case, device=DEV)
+    model, _ = build(cfg, wseed, case)
+    g = load_golden(case)
+    want = g["proposal_centers_hdn"]                                             # HDN's output, before JLN rewrites [..., 4]
+    X = cfg.CAPTURE_SPEC.VOXELS_PER_AXIS[0]
+    flat = g["topk_flat"]
+    idx = np.stack([flat // X, flat % X, np.argmax(g["hm1d"], axis=2)], axis=-1)  # get_index2D's divisor quirk (:13-33)
+    layer = model.pose_net.proposal_layer
+    for dt in (torch.int64, torch.int32):
+        got = layer(torch.from_numpy(idx).to(DEV, dt), torch.from_numpy(want[..., 4]).to(DEV),
+                    torch.from_numpy(np.ascontiguousarray(want[..., 5:7])).to(DEV), meta)
+        assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
+    layer.train()
+    with pytest.raises(NotImplementedError):
+        layer(torch.from_numpy(idx).to(DEV), torch.from_numpy(want[..., 4]).to(DEV),
+              torch.from_numpy(np.ascontiguousarray(want[..., 5:7])).to(DEV), {"roots_3d": 0, "num_person": 0})
+    layer.eval()
+
+
+@pytest.mark.parametrize("name", ["panoptic_b8", "shelf_b2", "panoptic128_b1", "campus_b2", "panoptic_b32"])
 def test_float_parity_seed_sweep(name):
     """North-star float bar WITHOUT hand-picked seeds: 10 consecutive heatmap seeds per shape through the reference
     (tests/golden/make_seed_sweep.py), MIN_SCORE fixed at 0.4, Panoptic at the benchmark's own batch (B = 8), jln128
@@ -68,7 +93,11 @@ def test_float_parity_seed_sweep(name):
           Panoptic, jln128 and Shelf (round 4), reported for Campus, whose asserted float bar is the conditioned fixture
           campus_c_b2_thr (tests/common.py FLOOR_RULE);
       R2  every joint: |build - ref32| <= 3 x max(its proposal's floor, 4e-4) - never noisier than the reference;
-      proposal centres bit-equal; the overall fraction within 1e-3 mm goes to the parity report."""
+      proposal centres bit-equal; the overall fraction within 1e-3 mm goes to the parity report.
+    Round 5: (i) panoptic_b32 - the largest batch bench.py quotes a rate for - with the Panoptic rules; (ii) Campus: the
+    predicate of the conditioned Campus fixture (common.FLOOR_RULE: worst joint of a proposal within 2 x the proposal's own
+    reference fp32-vs-fp64 floor) evaluated on EVERY compared proposal of all 10 seeds instead of one hand-picked seed:
+    >= 95 % of the proposals must satisfy it and every one stays within 3 x (measured: 98 of 100, worst 2.77)."""
     import seed_sweep as SW
     s, rows = SW.replay(name, DEV, detail_path=os.path.join(os.path.dirname(REPORT), f"sweep_detail_{name}.npy"))
     rep = dict(s, case="sweep_" + name, rows=rows)
@@ -76,15 +105,18 @@ def test_float_parity_seed_sweep(name):
     with open(REPORT, "a") as f:
         f.write(json.dumps(rep) + "\n")
     print(rep)
-    assert s["seeds"] == SW.SEEDS and s["joints"] > 300
+    assert s["seeds"] == SW.seeds_of(name) and s["joints"] > 300
     assert s["centres_exact"], "proposal centres / valid flags differ from the reference"
-    if name in ("panoptic_b8", "panoptic128_b1"):
+    if name in ("panoptic_b8", "panoptic128_b1", "panoptic_b32"):
         assert s["violations_where_floor_le_4e-4"] == 0, s                       # R1
     assert s["violations_in_proposals_with_floor_le_4e-4"] == 0, s               # R1p
     if name != "campus_b2":
         assert s["violations_r1q"] == 0 and s["joints_r1q"] > 300, s             # R1q (Shelf: 910 joints in round 3)
     assert name == "campus_b2" or s["joints_of_proposals_with_floor_le_4e-4"] > 300
     assert s["worst_err_over_proposal_floor"] <= 3.0, s                          # R2
+    if name == "campus_b2":                                                      # FLOOR_RULE over the whole sweep
+        assert s["proposals"] >= 90 and s["proposals_within_2x_own_floor"] >= 0.95 * s["proposals"], s
+        assert s["worst_proposal_err_over_own_floor"] <= 3.0, s
 
 
 def test_fused_projection_equals_materialised_full_size():
@@ -307,6 +339,36 @@ def test_pipelined_forward_equals_plain_forward():
     for (f, p, c), ((gf, gp, gc, _, _), ev) in zip(want, got):
         assert ev.query()
         assert torch.equal(f, gf) and torch.equal(p, gp) and torch.equal(c, gc)
+
+
+@pytest.mark.gpu
+def test_graphed_pipeline_equals_plain_forward():
+    """FV.GraphedPipeline (one hipGraph per pipeline slot, static input buffer per slot): 10 batches through 3 slots equal
+    the plain forward bit for bit; a slot's outputs stay valid until the slot comes round again."""
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = S.make_cfg("panoptic", device="cuda:0", min_score=-1.0)
+    cams, seq = S.load_cameras("panoptic")
+    rt = S.resize_transform(cfg).to("cuda:0")
+    model = FV.get(cfg).to("cuda:0")
+    model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=17))
+    heats = [S.heatmaps_blobs(cfg, cams, seq, 2, people=3, seed=60 + i).to("cuda:0") for i in range(5)]
+    meta = {"seq": [seq] * 2}
+    with torch.no_grad():
+        want = []
+        for h in heats:
+            f, p, c, _, _ = model(meta=meta, input_heatmaps=h, cameras=cams, resize_transform=rt)
+            want.append((f.clone(), p.clone(), c.clone()))
+        torch.cuda.synchronize()
+        gp = FV.GraphedPipeline(model, 3, meta, heats[0], cams, rt)
+        got = []
+        for i in range(10):
+            (f, p, c, _, _), ev = gp.submit(heats[i % 5])
+            ev.synchronize()                             # (the slot's static outputs: copy before the slot is reused)
+            got.append((f.clone(), p.clone(), c.clone()))
+        gp.synchronize()
+    for i, (f, p, c) in enumerate(got):
+        w = want[i % 5]
+        assert torch.equal(f, w[0]) and torch.equal(p, w[1]) and torch.equal(c, w[2]), i
 
 
 @pytest.mark.gpu

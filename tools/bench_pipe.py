@@ -27,6 +27,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--streams", type=int, default=4)
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--graph", action="store_true", help="one hipGraph per pipeline slot (FV.GraphedPipeline)")
 a = ap.parse_args()
 dev = "cuda:0"
 cfg = S.make_cfg(a.config, device=dev, min_score=-1.0)
@@ -36,7 +37,18 @@ heats = [S.heatmaps_blobs(cfg, cams, seq, a.batch, people=4, seed=100 + i).to(de
 meta = {"seq": [seq] * a.batch}
 model = FV.get(cfg).to(dev)
 model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
-pipe = FV.PipelinedForward(model, depth=a.streams)
+if a.graph:
+    gp = FV.GraphedPipeline(model, a.streams, meta, heats[0], cams, rt)
+
+    class _P:                                            # same submit signature as PipelinedForward
+        def submit(self, **kw):
+            return gp.submit(kw["input_heatmaps"])
+
+        def synchronize(self):
+            gp.synchronize()
+    pipe = _P()
+else:
+    pipe = FV.PipelinedForward(model, depth=a.streams)
 with torch.no_grad():
     for i in range(6):
         pipe.submit(meta=meta, input_heatmaps=heats[i % 4], cameras=cams, resize_transform=rt)
@@ -55,4 +67,4 @@ with torch.no_grad():
         rates.append(a.steps * a.batch / (t2 - t0))
         subs.append((1e3 * (t1 - t0) / a.steps, 1e3 * (t2 - t1)))
 print(f"   host submit ms/step, drain ms: " + " ".join(f"{x:.3f}/{y:.2f}" for x, y in subs))
-print(f"{os.path.basename(capi.LIB_PATH)}: {a.config} B={a.batch} x{a.streams}: frames/s " + " ".join(f"{x:.0f}" for x in rates))
+print(f"{os.path.basename(capi.LIB_PATH)}: {a.config} B={a.batch} x{a.streams}{' hipGraph slots' if a.graph else ''}: frames/s " + " ".join(f"{x:.0f}" for x in rates))
