@@ -865,7 +865,7 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   // (diagnostics build) keeps the staged quad form for comparison; both give the same bits.
   if (!gather && nvl == 2 && !quad_form && !staged) {
     const int nbx2 = ceil_div(C, kBlkBX);
-    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * 16) * g->JP * 4;
+    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * 16) * (g->JP + 1) * 4;   // cell pitch JP + 1
     if (fine_grid)
       hipLaunchKernelGGL((k_project_triplane_blk<2, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
                          reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
@@ -878,7 +878,7 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   }
   if (!gather && nvl == 1 && !quad_form && !staged && g->JP == 16) {
     const int nbx2 = ceil_div(C, kBlkBX);
-    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * kBlkBZ) * g->JP * 4;
+    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * kBlkBZ) * (g->JP + 1) * 4;   // cell pitch JP + 1
     if (fine_grid)
       hipLaunchKernelGGL((k_project_triplane_blk<1, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
                          reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,

@@ -614,10 +614,16 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
     if (acc[0][0][0] != 1.2345e-30f) continue;
 #endif
     // ---- block maxima through LDS, then into the global planes (as k_project_triplane_lds)
-    int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JP]
-    int* cxz = cxy + kBX * kBY * JP;                                     // [kBX][BZ][JP]
-    int* cyz = cxz + kBX * BZ * JP;                                      // [kBY][BZ][JP]
-    const int ncell = (kBX * kBY + (kBX + kBY) * BZ) * JP;
+    // Cell rows are JPp = JP + 1 words apart (round 5): with the natural pitch of 16 the lanes of an atomic instruction -
+    // (channel quad q, z phase zs, y) -> word (cell * 16 + 4 q + c) - fall on 8 of the 32 banks (z phases 0 / 2 and the
+    // y pairs of a 32-lane group share them): SQ_LDS_BANK_CONFLICT was 7.6 cycles per LDS instruction of this kernel.
+    // With the odd pitch the 32 lanes of a group hit 32 different banks; only the same-address pairs of the x-z cells
+    // (the two y lanes of a group) still serialise.
+    const int JPp = JP + 1;
+    int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JPp]
+    int* cxz = cxy + kBX * kBY * JPp;                                    // [kBX][BZ][JPp]
+    int* cyz = cxz + kBX * BZ * JPp;                                     // [kBY][BZ][JPp]
+    const int ncell = (kBX * kBY + (kBX + kBY) * BZ) * JPp;
     __syncthreads();                                                     // (the previous z block's readers are done)
     for (int i = t; i < ncell; i += NT) cxy[i] = 0;
     __syncthreads();
@@ -633,8 +639,8 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
           mz = fmaxf(mz, val);
           if (val > 0.0f && ch < JP) {
             const int z = zs + 4 * i;
-            atomicMax(&cxz[(xx * BZ + z) * JP + ch], __float_as_int(val));
-            atomicMax(&cyz[(yy * BZ + z) * JP + ch], __float_as_int(val));
+            atomicMax(&cxz[(xx * BZ + z) * JPp + ch], __float_as_int(val));
+            atomicMax(&cyz[(yy * BZ + z) * JPp + ch], __float_as_int(val));
           }
         }
         // (reducing the four y lanes of an (x, z) cell with DPP row rotates before one of them touches LDS - lanes as
@@ -642,13 +648,13 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
         int mi = __float_as_int(mz);
         mi = imax(mi, dpp_i<0x124>(mi));
         mi = imax(mi, dpp_i<0x128>(mi));
-        if (zs == 0 && mi > 0 && ch < JP) cxy[(xx * kBY + yy) * JP + ch] = mi;
+        if (zs == 0 && mi > 0 && ch < JP) cxy[(xx * kBY + yy) * JPp + ch] = mi;
       }
     __syncthreads();
     const int lz0 = gz0 - tl2;
     for (int i = t; i < kBX * kBY * J; i += NT) {
       const int ch = i / (kBX * kBY), col = i - ch * (kBX * kBY), cx = col / kBY, cy = col - cx * kBY;
-      const int raw = cxy[col * JP + ch];
+      const int raw = cxy[col * JPp + ch];
       if (raw > 0 && gx0 + cx < e0 && gy0 + cy < e1) {
         const int vv = __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f));
         if (vv > 0) plane_max(&pxy[size_t(ch) * CC + (gx0 + cx - tl0) * C + (gy0 + cy - tl1)], vv);
@@ -657,7 +663,7 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
     for (int i = t; i < (kBX + kBY) * BZ * J; i += NT) {
       const int ch = i / ((kBX + kBY) * BZ), r = i - ch * ((kBX + kBY) * BZ), a = r / BZ, z = r - a * BZ;
       if (gz0 + z < e2) {
-        const int raw = cxz[r * JP + ch];
+        const int raw = cxz[r * JPp + ch];
         const int vv = raw > 0 ? __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f)) : 0;
         if (vv > 0) {
           if (a < kBX) {

@@ -36,6 +36,7 @@ FP64_EXCEPTIONS = {"tiny_u_b3_thr": 3e-3, "campus_u_b2_all": 4e-3, "panoptic_u_b
 # run of this fixture; the CPU emulation of the kernels gave worst ratios 1.26 / 1.71 (9 proposals, pfloor 0.96e-3 .. 1.97e-3,
 # |build - ref32| max 2.0e-3 mm: the literal 1e-3 mm bar is NOT met on Campus, by the reference's fp32 path either).
 FLOOR_RULE = {"campus_c_b2_thr": (1.5, 2.0)}
+FLOOR_RULE_ABS_MM = 2.5e-3
 
 
 def floor_rule_check(case, xyz, g, report=None):
@@ -52,6 +53,9 @@ def floor_rule_check(case, xyz, g, report=None):
         report.update(worst_ratio_vs_fp64=float(r64.max()), worst_ratio_vs_ref32=float(r32.max()),
                       proposal_floor_min_mm=float(pfl[v].min()), proposal_floor_max_mm=float(pfl[v].max()))
     assert pfl[v].min() > 5e-4, "fixture no longer needs the floor rule"
+    # an absolute ceiling beside the ratio bars: a regression that scales with the proposals' own floors
+    # cannot hide behind them (measured on the MI355X: 1.97e-3 mm)
+    assert d32.max(axis=-1)[v].max() <= FLOOR_RULE_ABS_MM, f"{case}: |build-ref32| max {d32.max(axis=-1)[v].max():.2e} mm"
     assert r64.max() <= k64 and r32.max() <= k32, \
         f"{case}: |build-ref64| / pfloor max {r64.max():.2f} (bar {k64}), |build-ref32| / pfloor max {r32.max():.2f} (bar {k32})"
     return float(r64.max()), float(r32.max())
