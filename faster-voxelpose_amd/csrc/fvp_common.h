@@ -9,6 +9,8 @@
 #ifndef FVP_OPAQUE
 #define FVP_OPAQUE(x) asm volatile("" : "+s"(x))
 // two wave-uniform values made opaque together, optionally ordered after the computation of a vector value
+// the same for a per-lane value (keeps loop-invariant unpacking of a packed register out of the live set)
+#define FVP_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #define FVP_OPAQUE_PAIR(s0, s1) asm volatile("" : "+s"(s0), "+s"(s1))
 #define FVP_OPAQUE_PAIR_AFTER(s0, s1, vdep) asm volatile("" : "+s"(s0), "+s"(s1) : "v"(vdep))
 #endif

@@ -62,18 +62,23 @@ constexpr unsigned kWinoOOB = 0x80000000u;   // offset bit that fails the buffer
 // stays resident in LDS behind the three input slots (loaded once per persistent workgroup) instead of
 // streaming through the slots chunk by chunk: for the 32-channel layers the weight chunks were more than
 // half of the LDS-DMA traffic of a unit.
-template <int WC, int WT, int CC, int NI, bool HAS_RES, bool RESW>
-__global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
+// CW = cout blocks (of 16) per wave: 2 = the 128-accumulator wave tile above (two waves per SIMD); 1 = 16 couts x 16 tiles,
+// 64 accumulators, <= 128 registers: a 16-wave workgroup, FOUR waves per SIMD (round 5: more waves to cover each other's
+// LDS / DMA / barrier waits, at twice the patch transforms per MFMA).  WC = wave groups along the couts.
+template <int WC, int WT, int CC, int NI, bool HAS_RES, bool RESW, int CW = 2>
+__global__ void __launch_bounds__(WC * WT * 64, (WC * WT == 16 ? 4 : 2)) k_conv_wino(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
-  constexpr int NWV = WC * WT;                       // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+  constexpr int NWV = WC * WT;                       // waves per workgroup: 8 / 16 (one workgroup per CU) or 4 (two per CU)
   constexpr int NT = NWV * 64;
-  static_assert(NWV == 8 || NWV == 4, "4 or 8 waves");
+  static_assert(NWV == 16 || NWV == 8 || NWV == 4, "4, 8 or 16 waves");
+  static_assert(CW == 1 || CW == 2, "cout blocks per wave");
   static_assert(CC == 4 || CC == 8, "chunk");
   static_assert(NI >= 1 && NI <= 4, "input DMA rounds");
-  constexpr int CBW = 32 * WC;
+  constexpr int CBW = 16 * CW * WC;                  // couts of the workgroup
   constexpr int WCH = CC * CBW * 16;                 // floats of one weight chunk
   constexpr int WS_SZ = RESW ? 0 : WCH;              // ... streamed through a slot
-  constexpr int NW = RESW ? 0 : CC * WC * 2 / NWV;   // weight DMA instructions per wave per chunk
+  constexpr int NW = RESW ? 0 : CC * CBW * 4 / NT;   // weight DMA instructions per wave per chunk
+  static_assert(RESW || (CC * CBW * 4) % NT == 0, "whole weight DMA rounds");
   constexpr int NPS = NI + NW;                       // DMA instructions per wave per chunk
   constexpr int S = CC / 4;                          // steps (4 channels) per chunk
   constexpr int XS_SZ = NI * NT * 4;                 // input slot: NI rounds of one 16-byte item per thread (floats)
@@ -120,21 +125,28 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // this lane's 2x2 output tile inside the workgroup tile: TN planes x TR rows x tpr tiles; lanes beyond that
   // product (row lengths that do not divide 16*WT) compute on tile 0's data and store nothing
   const int q0 = wt * 16 + l15;
-  const bool q_ok = q0 < a.TN * a.tpp;
-  const int q = q_ok ? q0 : 0;
-  const int tn = fdiv_nb(q, a.m_tpp), trem = q - tn * a.tpp;
-  const int ty = fdiv_nb(trem, a.m_tpr), tx = trem - ty * a.tpr;
-  // LDS row 0 of the tile is image row y0 - 1; column 4 of a row slot is image x = 0
-  const int poff = tn * plane_sz + 2 * ty * WP + 3 + 2 * tx + k4 * CS;
+  int poff;
+  {
+    const bool q_ok = q0 < a.TN * a.tpp;
+    const int q = q_ok ? q0 : 0;
+    const int tn = fdiv_nb(q, a.m_tpp), trem = q - tn * a.tpp;
+    const int ty = fdiv_nb(trem, a.m_tpr), tx = trem - ty * a.tpr;
+    // LDS row 0 of the tile is image row y0 - 1; column 4 of a row slot is image x = 0
+    poff = tn * plane_sz + 2 * ty * WP + 3 + 2 * tx + k4 * CS;
+  }
   const int swz = (l15 >> 2) & 3;
-  int aoff[4];                                       // cout block cb adds 16 rows = 256 floats
+  // A operand of quad xi: float index ((row * 4 + (xi ^ swz)) * 4 = a0 ^ (xi << 2), a0 = row * 16 + swz * 4 (cout block cb adds
+  // 16 rows = 256 floats).  The two-block form keeps the four offsets in registers; the one-block form (128 registers in all)
+  // keeps a0 and pays three XORs per fetch.
+  const int a0 = (k4 * CBW + wc * (16 * CW) + l15) * 16 + swz * 4;
+  int aoff[4];
 #pragma unroll
-  for (int xi = 0; xi < 4; ++xi) aoff[xi] = ((k4 * CBW + wc * 32 + l15) * 4 + (xi ^ swz)) * 4;
+  for (int xi = 0; xi < 4; ++xi) aoff[xi] = a0 ^ (xi << 2);
   const float* const wres = smem + 4 + 3 * BUF_SZ;   // RESW: resident weights [cinp][CBW][16]
   // first weight float of chunk k living in slot `slot` (streamed) or in the resident copy
   auto wchunk = [&](const float* slot, int k) { return RESW ? wres + k * WCH : slot + XS_SZ; };
 
-  f32x4 acc[2][16];
+  f32x4 acc[CW][16];
 
   const int HW = a.H * W;
   const int nchunks = a.cinp / CC;
@@ -145,28 +157,32 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   // channel 0 of the chunk, one row above the band) is unit-independent; whether it lies inside the image depends on
   // the unit's band (top / bottom rows) and plane group (last, partial one).  Bit 31 = outside: the buffer range check
   // fails and the hardware writes zeros to LDS (tools/micro/buflds.hip) - no zero page, no select, no vector
-  // instruction per chunk.  tag = row in band (9 bits; 511 = never inside: fails the row test for every H <= 510) |
-  // plane in group (7 bits).
+  // instruction per chunk.  The item's (row, plane) is recomputed from the lane number when the cursor enters a unit
+  // (a dozen vector instructions per item and unit) rather than kept in a register.
   unsigned voff[NI];
-  unsigned tag[(NI + 1) / 2];
-  {
+  // (row in band, plane in group) of input item j of this lane, or row 511 = never inside (fails the row test for H <= 510)
+  auto item_pos = [&](int j, int& ry, int& n, bool& inside, int& ci, int& qd) {
     const int qpr = (W >> 2) + 1;
     const int rows_per_ch = a.TN * THp;
     const int nin = CC * rows_per_ch * qpr + 1;      // + the zero quad behind the last row
+    int ln = lane;
+    FVP_OPAQUE_V(ln);                                // (recomputed where it is used: per unit, not kept in registers)
+    const int it = (wave + NWV * j) * 64 + ln;
+    const int row = fdiv_nb(it, a.m_qpr);
+    qd = it - row * qpr;
+    ci = fdiv_nb(row, a.m_rpc);
+    const int rem = row - ci * rows_per_ch;
+    n = fdiv_nb(rem, a.m_thp);
+    ry = rem - n * THp;
+    inside = it < nin && qd > 0 && ci < CC;
+  };
 #pragma unroll
-    for (int j = 0; j < (NI + 1) / 2; ++j) tag[j] = 0;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int it = (wave + NWV * j) * 64 + lane;
-      const int row = fdiv_nb(it, a.m_qpr), qd = it - row * qpr;
-      const int ci = fdiv_nb(row, a.m_rpc);
-      const int rem = row - ci * rows_per_ch;
-      const int n = fdiv_nb(rem, a.m_thp), ry = rem - n * THp;
-      const bool inside = it < nin && qd > 0 && ci < CC;
-      voff[j] = inside ? unsigned((n * a.cin + ci) * HW + ry * W + 4 * (qd - 1)) * 4u : 0u;
-      const unsigned tg = inside ? unsigned(ry) | (unsigned(n) << 9) : 511u;
-      tag[j >> 1] |= tg << (16 * (j & 1));
-    }
+  for (int j = 0; j < NI; ++j) {
+    int ry, n, ci, qd;
+    bool inside;
+    item_pos(j, ry, n, inside, ci, qd);
+    voff[j] = inside ? unsigned((n * a.cin + ci) * HW + ry * W + 4 * (qd - 1)) * 4u : 0u;
+    __builtin_amdgcn_sched_barrier(0);
   }
   // this lane's weight item j: channel ci0 + j * DCI of the chunk, quad qd0 of the cout block's row
   constexpr int DCI = NT / (CBW * 4);
@@ -194,10 +210,12 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
     set_base(rs_w, ka->wts + size_t(sy) * (CBW * 16));
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const unsigned tg = tag[j >> 1] >> (16 * (j & 1));
-      const int ry = int(tg & 0x1ffu), n = int((tg >> 9) & 0x7fu);
-      const bool ok = unsigned(sy0 + ry - 1) < unsigned(H) && splane0 + n < planes;
+      int ry, n, ci, qd;
+      bool inside;
+      item_pos(j, ry, n, inside, ci, qd);
+      const bool ok = inside && unsigned(sy0 + ry - 1) < unsigned(H) && splane0 + n < planes;
       voff[j] = (voff[j] & 0x7fffffffu) | (ok ? 0u : kWinoOOB);
+      __builtin_amdgcn_sched_barrier(0);             // one item at a time: the items' temporaries must not pile up (16-wave form: 128 registers)
     }
   };
   // every wave issues exactly NPS DMA instructions per chunk (counted s_waitcnt vmcnt below)
@@ -225,14 +243,16 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
   };
 
   // ---- operand fetch / transform / MFMA building blocks
-  float4 av[2][4];
+  float4 av[CW][4];
   float d[4][4];                                     // the lane's 4x4 patch
   float v[4][4];                                     // V[xi][nu] = B^T d B
   auto fetch_a = [&](int cb, const float* wbase, int s) {     // wbase = weights of the chunk, s = step in chunk
     if (kDiag && (ablate & 256)) return;                      // diagnostics: no A-operand reads
+    int a0o = a0;
+    if (CW == 1) FVP_OPAQUE_V(a0o);                  // (recomputed per fetch: hipcc would hoist the four offsets again)
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi)
-      av[cb][xi] = *reinterpret_cast<const float4*>(wbase + aoff[xi] + (s * 4 * CBW * 16 + cb * 256));
+      av[cb][xi] = *reinterpret_cast<const float4*>(wbase + (CW == 1 ? (a0o ^ (xi << 2)) : aoff[xi]) + (s * 4 * CBW * 16 + cb * 256));
   };
   auto fetch_d = [&](const float* base, int s, int wp) {
     const float* xs = base + poff + s * 4 * CS;
@@ -320,6 +340,7 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       const float* const ns = slot_ptr(nxt);
       int wp = WP;
       FVP_OPAQUE(wp);
+      if constexpr (CW == 2) {
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         // ---- half-step 0: patch transform, cout block 0
@@ -368,6 +389,42 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         else mfma16(1, std::integral_constant<bool, false>{});
         __builtin_amdgcn_sched_barrier(0);
       }
+      } else {
+        // ---- one cout block per wave (four waves per SIMD): per step  wait - transform - 16 MFMAs - request the next
+        // step's operands.  Nothing is double-buffered (patch, V and the next patch share 16 registers: with the next
+        // patch in flight beside V the wave would need 128 registers before anything else): the other three waves of the
+        // SIMD cover the LDS latency.
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): av[0] and the patch have landed
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            float tr[4][4];
+            transform(tr);
+            columns(tr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (kFirst && s == 0) mfma16(0, std::integral_constant<bool, true>{});
+          else mfma16(0, std::integral_constant<bool, false>{});
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < S) {
+            fetch_a(0, wchunk(cs, k), s + 1);
+            fetch_d(cs, s + 1, wp);
+          } else {
+            // (chunk barrier: see the two-block form above; no LDS read of this slot is pending here)
+            if (!kFirst && dma) {
+              if (more) wait_vmcnt_imm<NPS>();
+              else wait_vmcnt_imm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (k + 1 < nchunks) {
+              fetch_a(0, wchunk(ns, k + 1), 0);
+              fetch_d(ns, 0, wp);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       cur = nxt;
     };
     chunk(0, std::integral_constant<bool, true>{});
@@ -386,7 +443,16 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       float* const dst = ka->dst;
       const float* const res = ka->res;
       float* const pool_dst = ka->pool_dst;
-      // per lane: tile (plane, y, x), 8 couts
+      // per lane: tile (plane, y, x), 8 (or 4) couts; the tile coordinates are recomputed from the lane's tile number here
+      // instead of living in three registers across the K loop
+      int le = lane;
+      FVP_OPAQUE_V(le);
+      const int k4 = le >> 4;
+      const int qe = wt * 16 + (le & 15);
+      const bool q_ok = qe < ka->TN * ka->tpp;
+      const int qq = q_ok ? qe : 0;
+      const int tn = fdiv_nb(qq, ka->m_tpp), trem = qq - tn * ka->tpp;
+      const int ty = fdiv_nb(trem, ka->m_tpr), tx = trem - ty * ka->tpr;
       const bool relu = flags & FVP_EPI_RELU;
       const bool res_after = flags & FVP_EPI_RES_AFTER_RELU;
       const int plane = plane0 + tn, y = y0 + 2 * ty, x = 2 * tx;
@@ -401,10 +467,10 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
       // element offset of (cout co4 + r, this lane's tile); padded couts and masked tiles read a valid address and store nothing
       const unsigned omask = (kDiag && (ablate & 1024)) ? 0x3ffffu : ~0u;   // (bit 1024, diagnostics: epilogue traffic stays inside 1 MB)
       auto out_off = [&](int co) { return ((cbase + (tile_ok && co < cout ? co : 0)) * unsigned(HW) + pix) & omask; };
-      float2 r0[2][4], r1[2][4];
+      float2 r0[CW][4], r1[CW][4];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const int co4 = co0 + wc * 32 + cb * 16 + 4 * k4;
+      for (int cb = 0; cb < CW; ++cb) {
+        const int co4 = co0 + wc * (16 * CW) + cb * 16 + 4 * k4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const unsigned off = out_off(co4 + r);
@@ -419,9 +485,9 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         }
       }
       // output transform A^T M A of the 8 couts while the residual loads are in flight (the accumulators die here)
-      float o[2][4][2][2];
+      float o[CW][4][2][2];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < CW; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float s[4][2];
@@ -454,10 +520,10 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         // kFast: BN (+ residual) -> ReLU and every cout of the block exists (cout % 32 == 0): one predicate (the lane's tile)
         // for all stores, no per-cout compare, no select in the addresses (masked lanes compute on plane 0 / pixel 0)
         constexpr bool kFast = decltype(fast)::value;
-        float vv[2][4][2][2];
+        float vv[CW][4][2][2];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          const int co4 = co0 + wc * 32 + cb * 16 + 4 * k4;
+        for (int cb = 0; cb < CW; ++cb) {
+          const int co4 = co0 + wc * (16 * CW) + cb * 16 + 4 * k4;
           f32x4 bn[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i) bn[i] = *reinterpret_cast<const f32x4*>(epi_s + i * coutp + co4);
@@ -489,10 +555,10 @@ __global__ void __launch_bounds__(WC * WT * 64, 2) k_conv_wino(ConvArgs a) {
         }
         if (kFast && tile_ok) {
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < CW; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int co = co0 + wc * 32 + cb * 16 + 4 * k4 + r;
+              const int co = co0 + wc * (16 * CW) + cb * 16 + 4 * k4 + r;
               const unsigned off = (cbase + unsigned(co)) * unsigned(HW) + pix;
               *reinterpret_cast<float2*>(dst + off) = make_float2(vv[cb][r][0][0], vv[cb][r][0][1]);
               *reinterpret_cast<float2*>(dst + off + W) = make_float2(vv[cb][r][1][0], vv[cb][r][1][1]);
@@ -563,6 +629,9 @@ static const int kWinoWC1 = int(env_size("FVP_WINO_WC1", 0));        // diagnost
 static const int kWinoHalf = int(env_size("FVP_WINO_HALF", 0));
 static const int kWinoNoResW = int(env_size("FVP_WINO_NO_RESW", 0)); // diagnostics: stream the weights of the 32-channel layers too
 static const int kWinoAblate = int(env_size("FVP_CONV_ABLATE", 0));
+#ifndef FVP_WINO_W16_DEFAULT
+#define FVP_WINO_W16_DEFAULT 0
+#endif
 
 int persistent_workgroups() {
   static int n = 0;
@@ -608,10 +677,10 @@ bool wino_shape_ok(int h, int w, int cinp, int coutp) {
   return wino_tiling(h, w, cinp, coutp, &WC, &WT, &TN, &TR);
 }
 
-template <int WC, int WT, int CC, int NI, bool RES, bool RESW>
+template <int WC, int WT, int CC, int NI, bool RES, bool RESW, int CW = 2>
 static int launch_wino3(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static LdsOptIn optin;
-  auto k = &k_conv_wino<WC, WT, CC, NI, RES, RESW>;
+  auto k = &k_conv_wino<WC, WT, CC, NI, RES, RESW, CW>;
   if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), 160 * 1024)) return e;
   hipLaunchKernelGGL(k, grid, dim3(WC * WT * 64), lds, s, a);
   return launch_status();
@@ -627,6 +696,18 @@ static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s)
   }
   return FVP_ELIMIT;
 }
+#if FVP_DIAG
+// 16-wave form (one 16-cout block per wave, four waves per SIMD): CC = 8, one or two input DMA rounds
+template <int WC, int WT, bool RESW>
+static int launch_wino16(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  const bool res = a.flags & FVP_EPI_RES;
+  if (a.wino_ni == 1)
+    return res ? launch_wino3<WC, WT, 8, 1, true, RESW, 1>(a, grid, lds, s) : launch_wino3<WC, WT, 8, 1, false, RESW, 1>(a, grid, lds, s);
+  if (a.wino_ni == 2)
+    return res ? launch_wino3<WC, WT, 8, 2, true, RESW, 1>(a, grid, lds, s) : launch_wino3<WC, WT, 8, 2, false, RESW, 1>(a, grid, lds, s);
+  return FVP_ELIMIT;
+}
+#endif
 template <int WC, int WT>
 static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, bool resw) {
   if (WC == 1 && WT == 8 && resw && a.CC == 8) return launch_wino2<1, 8, 8, true>(a, grid, lds, s);
@@ -645,6 +726,18 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
       WC = wc; WT = wt; TN = tn; TR = tr;
     }
   }
+  // 16-wave form (one 16-cout block per wave, four waves per SIMD) for full-size units: instantiated in the diagnostics
+  // build only (FVP_WINO_W16=1).  Measured in round 5, same box, P2PNet at B = 8: the 64- / 128-channel layers 7 % SLOWER
+  // than the two-block form (139 -> 146, 111 -> 120 us: twice the patch transforms per MFMA outweigh the better latency
+  // cover), the 32-channel residual layers 8 % faster on a box with slow memory; the product keeps the two-block form.
+#if FVP_DIAG
+  static const int kW16 = int(env_size("FVP_WINO_W16", FVP_WINO_W16_DEFAULT));
+#else
+  constexpr int kW16 = 0;
+#endif
+  const bool w16 = kW16 && WC * WT == 8 && op.cinp % 8 == 0;
+  const int CW = w16 ? 1 : 2;
+  if (w16) WC *= 2;                                  // wave groups along the couts: 16 couts each
   a.ablate = kWinoAblate;
   a.wts = params + op.wino_off;
   a.TN = TN;
@@ -660,7 +753,7 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   a.zeros = params;
   // the tag of a DMA item holds its row in the band in 9 bits (511 = never inside) and its plane in the group in 7
   if (a.TH + 2 > 510 || op.h > 510 || TN > 127) return FVP_ELIMIT;
-  const int CBW = 32 * WC;
+  const int CBW = 16 * CW * WC;
   // channels per chunk: 8 when it divides cinp and three slots fit, else 4
   // resident weights: one 32-cout block covers all couts and [cinp][32][16] fits beside the three input slots
   const size_t resw_bytes = size_t(op.cinp) * CBW * 64;
@@ -670,7 +763,7 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   a.nflags = (a.plane_valid && TN == 1) ? ceil_div(planes, a.valid_div) : 0;
   a.m_vd = make_magic(a.valid_div);
   const size_t flag_bytes = size_t(a.nflags + 15) & ~size_t(15);
-  bool resw = WC == 1 && WT == 8 && op.coutp == 32 && op.cinp % 8 == 0 && resw_bytes <= 64 * 1024 && !kWinoNoResW;
+  bool resw = CBW == 32 && WT == 8 && op.coutp == 32 && op.cinp % 8 == 0 && resw_bytes <= 64 * 1024 && !kWinoNoResW;
   auto slot_bytes = [&](int cc, int* ni, bool rw) {
     const size_t quads = size_t(cc) * TN * (a.TH + 2) * (op.w / 4 + 1) + 1;
     const size_t per_round = size_t(WC) * WT * 64;       // one 16-byte item per thread and round
@@ -706,6 +799,13 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   // suits the other streams' large kernels better.)
   dim3 grid(std::min(a.nunits, persistent_workgroups() * (WC * WT == 4 ? 2 : 1)), 1, 1);
   ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
+#if FVP_DIAG
+  if (w16) {
+    if (CC != 8 || ni > 2) return FVP_ELIMIT;        // (shapes outside the 16-wave instances)
+    if (CBW == 32) return resw ? launch_wino16<2, 8, true>(a, grid, lds, s) : launch_wino16<2, 8, false>(a, grid, lds, s);
+    return launch_wino16<4, 4, false>(a, grid, lds, s);
+  }
+#endif
   if (WC * WT == 4) return launch_wino<1, 4>(a, grid, lds, s, false);
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false);
 }

@@ -26,6 +26,7 @@
 
 #define HIPEMU 1
 #define FVP_OPAQUE(x) ((void)0)
+#define FVP_OPAQUE_V(x) ((void)0)
 #define FVP_OPAQUE_PAIR(s0, s1) ((void)0)
 #define FVP_OPAQUE_PAIR_AFTER(s0, s1, vdep) ((void)0)
 #define __global__

@@ -52,7 +52,7 @@ def _alternate(r):
 def test_library_holds_the_expected_kernels(rows):
     names = " ".join(r["demangled"] for r in rows)
     assert len(rows) >= 150
-    for k in ("k_conv_wino<2, 4, 8, 2, true, false>", "k_conv_reg<128, 4, 1, true>", "k_conv_dma<7, 7, 1, 4, true",
+    for k in ("k_conv_wino<2, 4, 8, 2, true, false, 2>", "k_conv_reg<128, 4, 1, true>", "k_conv_dma<7, 7, 1, 4, true",
               "k_project_triplane_blk<1, true>", "k_project_whole_q", "k_conv1d_fused", "k_softargmax_weightnet",
               "k_bb_conv_dma"):
         assert k in names, k
