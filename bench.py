@@ -338,6 +338,9 @@ class StubWorkload:
         pass
 
 
+HOST_TIMES = {}       # of the most recent timed_region: host submit ms per step, drain ms
+
+
 def timed_region(wl, steps, warmup, dist_on, dev):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronisation on both
     sides; returns this rank's seconds and the last step's (gathered) output."""
@@ -356,6 +359,9 @@ def timed_region(wl, steps, warmup, dist_on, dev):
             out = wl.step(i)
         t_sub = time.perf_counter()
         wl.sync()                                # every stream of the device: compute pipeline and gathers
+        # host time spent enqueueing the K steps, and how long the GPU still ran afterwards (GPU-bound when the drain is
+        # long: the host is ahead of the device)
+        HOST_TIMES.update(submit_ms_per_step=1e3 * (t_sub - t0) / max(1, steps), drain_ms=1e3 * (time.perf_counter() - t_sub))
         if os.environ.get("FVP_BENCH_DEBUG"):
             print(f"[debug] submit {1e3 * (t_sub - t0):.2f} ms, drain {1e3 * (time.perf_counter() - t_sub):.2f} ms",
                   file=sys.stderr)
@@ -390,12 +396,44 @@ def secondary_leg(config, B, streams, steps, warmup, dev, backbone=False, serial
     dt, out = timed_region(wl, steps, warmup, False, dev)
     leg = {"config": config, "frames_per_step": B, "batches_in_flight": wl.nstreams, "steps": steps,
            "frames_per_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps,
-           "valid_people_per_frame": float((out[..., 0, 3] >= 0).sum().item()) / out.shape[0]}
+           "valid_people_per_frame": float((out[..., 0, 3] >= 0).sum().item()) / out.shape[0],
+           "host_submit_ms_per_step": HOST_TIMES.get("submit_ms_per_step"), "drain_ms": HOST_TIMES.get("drain_ms")}
     if serial:
         leg["frames_per_s_one_batch_at_a_time"] = serial_rate(wl, 1)
     del wl
     torch.cuda.empty_cache()
     return leg
+
+
+def graph_slots_leg(config, B, depth, steps, dev):
+    """The same pipeline with every slot captured as a hipGraph (FV.GraphedPipeline): frames/s and host submit time."""
+    import torch
+    import fvp_synthetic as S
+    from faster_voxelpose_amd.models import faster_voxelpose as FV
+    cfg = S.make_cfg(config, device=dev, min_score=-1.0)
+    cams, seq = S.load_cameras(config)
+    rt = S.resize_transform(cfg).to(dev)
+    heats = [S.heatmaps_blobs(cfg, cams, seq, B, people=4, seed=100 + i).to(dev) for i in range(4)]
+    model = FV.get(cfg).to(dev)
+    model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
+    with torch.no_grad():
+        gp = FV.GraphedPipeline(model, depth, {"seq": [seq] * B}, heats[0], cams, rt)
+        for i in range(2 * depth):
+            gp.submit(heats[i % 4])
+        gp.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            gp.submit(heats[i % 4])
+        t1 = time.perf_counter()
+        gp.synchronize()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    del gp, model
+    torch.cuda.empty_cache()
+    return {"config": config, "frames_per_step": B, "batches_in_flight": depth, "steps": steps, "launch": "one hipGraph per pipeline slot",
+            "frames_per_s": B * steps / (t2 - t0), "ms_per_step": 1e3 * (t2 - t0) / steps,
+            "host_submit_ms_per_step": 1e3 * (t1 - t0) / steps, "drain_ms": 1e3 * (t2 - t1)}
 
 
 def load_pmc_traffic(top, B, config):
@@ -485,6 +523,9 @@ def main():
         gatherer.synchronize()
         dist.barrier()
     dt, out = timed_region(wl, args.steps, args.warmup, dist_on, dev)
+    headline_host = {"submit_ms_per_step": HOST_TIMES.get("submit_ms_per_step"), "drain_ms": HOST_TIMES.get("drain_ms"),
+                     "what": "host time to enqueue one step of the timed region (Python + ctypes launches), and how long the "
+                             "GPU still ran after the last enqueue (long drain = the GPU, not the host, is the limit)"}
     assert out.shape[0] == B * world
     valid_people = float((out[..., 0, 3] >= 0).sum().item()) / out.shape[0]
 
@@ -581,7 +622,7 @@ def main():
             kern["per_step_ms"] = {nm: kern[nm]["ms_total"] / prof_steps for nm in names.values()}
 
         # ---- secondary legs (world size 1, default run): the other BASELINE configs through the same protocol
-        other, latency_b1, e2e = None, None, None
+        other, latency_b1, e2e, pipe_legs = None, None, None, None
         if not args.no_extra and world == 1 and not STUB and not args.backbone and not args.graph:
             del wl
             torch.cuda.empty_cache()
@@ -599,6 +640,11 @@ def main():
                 if args.config != "campus":
                     other["campus (BASELINE configs[0] shape): 3 views, J = 17, 80x80x20, jln64, B = 8"] = \
                         secondary_leg("campus", 8, args.streams, 20, 3, dev)
+                # launch path: B = 1 with four batches in flight (the reference's demo batch) and the headline shape, eager
+                # launches against one hipGraph per slot - is the host the limit?
+                pipe_legs = {"b1_eager": secondary_leg(args.config, 1, args.streams, 100, 8, dev, serial=False),
+                             "b1_graph_slots": graph_slots_leg(args.config, 1, args.streams, 100, dev),
+                             f"b{B}_graph_slots": graph_slots_leg(args.config, B, args.streams, 40, dev)}
                 leg = secondary_leg("panoptic", 8, 2, 10, 2, dev, backbone=True)
                 gf = BACKBONE_GFLOP_PER_VIEW * 5
                 e2e = dict(leg, what="BASELINE configs[4] shape on one GPU: 5 x [3,512,960] images per frame -> bf16 "
@@ -632,6 +678,7 @@ def main():
                        "input": ("5 x [3,512,960] images per frame -> bf16 Pose-ResNet-50 -> voxel path" if args.backbone
                                  else "heatmaps resident in HBM")},
             "value_long": value_long, "latency_ms_b1_serial": latency_b1,
+            "host": headline_host, "pipeline_launch_paths": pipe_legs,
             "mpjpe_vs_ref_mm": mpjpe, "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
             "other_configs": other, "e2e": e2e,
         }
