@@ -33,6 +33,18 @@ sys.path.insert(0, ROOT)
 # (default line + Shelf / 128x128x32 / Campus / end-to-end legs, ~20 streams, never destroyed), and the later legs lost 5-10 %
 # on shared queues again (Shelf 2 512 vs 2 678): 24.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+_STREAM_POOL = {}
+
+
+def stream_pool(dev, n):
+    """ONE set of compute streams per device for every pipeline this process builds (round 5): the legs run one after the
+    other, and streams are never destroyed - with a fresh set per leg the later legs ended up on shared hardware queues."""
+    import torch
+    pool = _STREAM_POOL.setdefault(str(dev), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak
@@ -284,7 +296,8 @@ class Workload:
         self.model.load_state_dict(S.fill_state_dict(self.model.state_dict(), seed=7))
         self.nstreams = max(1, nstreams)
         # batches in flight: FV.PipelinedForward = one replica (scratch buffers) + one HIP stream each
-        self.pipe = FV.PipelinedForward(self.model, depth=self.nstreams) if self.nstreams > 1 else None
+        self.pipe = (FV.PipelinedForward(self.model, depth=self.nstreams, streams=stream_pool(dev, self.nstreams))
+                     if self.nstreams > 1 else None)
         self.bb = self.views_all = self.graphed = None
         if backbone:
             from faster_voxelpose_amd.core import config as CFG
@@ -417,7 +430,7 @@ def graph_slots_leg(config, B, depth, steps, dev):
     model = FV.get(cfg).to(dev)
     model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
     with torch.no_grad():
-        gp = FV.GraphedPipeline(model, depth, {"seq": [seq] * B}, heats[0], cams, rt)
+        gp = FV.GraphedPipeline(model, depth, {"seq": [seq] * B}, heats[0], cams, rt, streams=stream_pool(dev, depth))
         for i in range(2 * depth):
             gp.submit(heats[i % 4])
         gp.synchronize()

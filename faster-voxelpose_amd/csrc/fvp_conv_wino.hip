@@ -45,6 +45,14 @@
 
 #include "fvp_conv_args.h"
 
+// Ablation switches of the kernel (FVP_CONV_ABLATE bits: 1 no DMA, 4 no MFMA, 8 no epilogue, 16 no residual loads, 32 no
+// stores, 128 no chunk barrier, 256 no A reads, 512 no input transform, 1024 epilogue traffic inside 1 MB) exist only in a
+// variant built with -DFVP_WINO_ABLATE=1 (tools/build_variant.sh): as run-time flags they cost the diagnostics build 43-87
+// spilled VGPRs per instance (round 5: its 32-channel layers ran at half speed, which distorted every A/B made through it).
+#ifndef FVP_WINO_ABLATE
+#define FVP_WINO_ABLATE 0
+#endif
+
 namespace fvp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -83,7 +91,7 @@ __global__ void __launch_bounds__(WC * WT * 64, (WC * WT == 16 ? 4 : 2)) k_conv_
   constexpr int S = CC / 4;                          // steps (4 channels) per chunk
   constexpr int XS_SZ = NI * NT * 4;                 // input slot: NI rounds of one 16-byte item per thread (floats)
   constexpr int BUF_SZ = XS_SZ + WS_SZ;              // one ring slot
-  constexpr bool kDiag = FVP_DIAG != 0;              // ablation switches exist in the diagnostics build only
+  constexpr bool kDiag = FVP_WINO_ABLATE != 0;       // ablation switches: a variant build only (see FVP_WINO_ABLATE)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int k4 = lane >> 4, l15 = lane & 15;
@@ -727,9 +735,9 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
     }
   }
   // 16-wave form (one 16-cout block per wave, four waves per SIMD) for full-size units: instantiated in the diagnostics
-  // build only (FVP_WINO_W16=1).  Measured in round 5, same box, P2PNet at B = 8: the 64- / 128-channel layers 7 % SLOWER
-  // than the two-block form (139 -> 146, 111 -> 120 us: twice the patch transforms per MFMA outweigh the better latency
-  // cover), the 32-channel residual layers 8 % faster on a box with slow memory; the product keeps the two-block form.
+  // build only (FVP_WINO_W16=1).  Measured in round 5, same box, P2PNet at B = 8, per launch: 64 -> 64 @32x32 98 -> 109 us,
+  // 128 -> 128 @16x16 85 -> 99 us, 32 -> 32 @64x64 with residual 119 -> 143 us, whole pass 1 916 -> 2 113 us, pipelined
+  // 3 150 -> 2 960 frames/s: twice the patch transforms and A reads per MFMA cost more than four waves per SIMD hide.
 #if FVP_DIAG
   static const int kW16 = int(env_size("FVP_WINO_W16", FVP_WINO_W16_DEFAULT));
 #else
