@@ -801,11 +801,11 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   a.nunits = a.tiles_y * ceil_div(planes, TN) * a.ysplit;
   a.m_ys = make_magic(a.ysplit);
   a.m_ty = make_magic(a.tiles_y);
-  // One workgroup per slot.  (A balanced grid - ceil(units / rounds) workgroups that all do the same number of units, 240
-  // instead of 256 for 240 planes, leaving 16 CUs to the other streams for the whole launch - measured 1.3 % SLOWER pipelined
-  // on every shape, round 5: the quarter of the workgroups that idles through the last round frees 64 CUs at once, which
-  // suits the other streams' large kernels better.)
-  dim3 grid(std::min(a.nunits, persistent_workgroups() * (WC * WT == 4 ? 2 : 1)), 1, 1);
+  // One workgroup per slot.  FVP_WINO_BALANCED=1 (diagnostics build): ceil(units / rounds) workgroups that all do the same
+  // number of units (240 instead of 256 for 240 planes), leaving 16 CUs to the other streams for the whole launch.
+  static const int kBalanced = int(env_size("FVP_WINO_BALANCED", 0));
+  const int slots = persistent_workgroups() * (WC * WT == 4 ? 2 : 1);
+  dim3 grid(kBalanced ? ceil_div(a.nunits, ceil_div(a.nunits, slots)) : std::min(a.nunits, slots), 1, 1);
   ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
 #if FVP_DIAG
   if (w16) {
