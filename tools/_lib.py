@@ -13,4 +13,7 @@ def select(capi):
         capi.LIB_PATH = os.path.abspath(os.environ["FVP_LIB"])
     elif any(k.startswith(_KNOBS) for k in os.environ) and os.path.isfile(diag):
         capi.LIB_PATH = diag
+    if os.environ.get("FVP_WINO_GENERIC") == "1":     # host mirror of the library's switch (weight-blob layout)
+        from faster_voxelpose_amd import netspec
+        netspec.WINO_GENERIC = True
     return capi.LIB_PATH
