@@ -693,14 +693,14 @@ static int launch_wino3(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s)
   hipLaunchKernelGGL(k, grid, dim3(WC * WT * 64), lds, s, a);
   return launch_status();
 }
-template <int WC, int WT, int CC, bool RESW>
+template <int WC, int WT, int CC, bool RESW, int CW = 2>
 static int launch_wino2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   const bool res = a.flags & FVP_EPI_RES;
   switch (a.wino_ni) {
-    case 1: return res ? launch_wino3<WC, WT, CC, 1, true, RESW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 1, false, RESW>(a, grid, lds, s);
-    case 2: return res ? launch_wino3<WC, WT, CC, 2, true, RESW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 2, false, RESW>(a, grid, lds, s);
-    case 3: return res ? launch_wino3<WC, WT, CC, 3, true, RESW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 3, false, RESW>(a, grid, lds, s);
-    case 4: return res ? launch_wino3<WC, WT, CC, 4, true, RESW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 4, false, RESW>(a, grid, lds, s);
+    case 1: return res ? launch_wino3<WC, WT, CC, 1, true, RESW, CW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 1, false, RESW, CW>(a, grid, lds, s);
+    case 2: return res ? launch_wino3<WC, WT, CC, 2, true, RESW, CW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 2, false, RESW, CW>(a, grid, lds, s);
+    case 3: return res ? launch_wino3<WC, WT, CC, 3, true, RESW, CW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 3, false, RESW, CW>(a, grid, lds, s);
+    case 4: return res ? launch_wino3<WC, WT, CC, 4, true, RESW, CW>(a, grid, lds, s) : launch_wino3<WC, WT, CC, 4, false, RESW, CW>(a, grid, lds, s);
   }
   return FVP_ELIMIT;
 }
@@ -744,7 +744,21 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   constexpr int kW16 = 0;
 #endif
   const bool w16 = kW16 && WC * WT == 8 && op.cinp % 8 == 0;
-  const int CW = w16 ? 1 : 2;
+  // Quarter-size units (round 5): when even the half-size units (32 couts x 64 tiles) fill less than a quarter of the
+  // chip's 512 slots - B = 1: the 128-channel 16x16 layers have 120 of them - a 4-wave workgroup takes 16 couts x 64 tiles
+  // (one 16-cout block per wave: the accumulation chain of a (cout, tile) is the same, so the bits are) and the launch's
+  // critical path, one unit, halves: 30 -> 23 us per launch, B = 1 serial 795 -> 822 frames/s (1.26 -> 1.22 ms) at 1 915 -> 1 883
+  // with four batches in flight.  Applied to every layer below half the slots (240 units: the 32- / 64-channel layers at
+  // B = 1 too) it reaches 825 serial but 1 845 in flight and costs B = 2 3 % (twice the patch transforms per MFMA on a chip that
+  // IS full then): threshold 1/4.
+  // FVP_WINO_QUARTER (diagnostics build): 0 = never, 1 = below a quarter of the slots (default), 2 = below half.
+  static const int kQuarter = int(env_size("FVP_WINO_QUARTER", 1));
+  bool quarter = false;
+  if (kQuarter && !w16 && WC * WT == 4 && op.cinp % 4 == 0) {
+    const long units_half = long(ceil_div(op.h / 2, TR)) * ceil_div(planes, TN) * (op.coutp / 32);
+    quarter = units_half * (kQuarter == 2 ? 1 : 2) < persistent_workgroups();
+  }
+  const int CW = (w16 || quarter) ? 1 : 2;
   if (w16) WC *= 2;                                  // wave groups along the couts: 16 couts each
   a.ablate = kWinoAblate;
   a.wts = params + op.wino_off;
@@ -814,6 +828,7 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
     return launch_wino16<4, 4, false>(a, grid, lds, s);
   }
 #endif
+  if (quarter) return a.CC == 8 ? launch_wino2<1, 4, 8, false, 1>(a, grid, lds, s) : launch_wino2<1, 4, 4, false, 1>(a, grid, lds, s);
   if (WC * WT == 4) return launch_wino<1, 4>(a, grid, lds, s, false);
   return WC == 1 ? launch_wino<1, 8>(a, grid, lds, s, resw) : launch_wino<2, 4>(a, grid, lds, s, false);
 }
