@@ -34,6 +34,24 @@ __device__ __forceinline__ void asm_buffer_load_lds16(unsigned la, unsigned vo, 
                : "memory", "m0");
 }
 
+// buffer_load_dwordx2 / buffer_store_dword(x2) ... offen through a raw descriptor held as four SGPRs (the Winograd
+// epilogue: the descriptor of the unit's first plane, ONE per-lane byte offset for every access of the lane and a scalar
+// byte offset per (cout, row) - no address arithmetic per access; a per-lane offset with bit 31 set fails the range check:
+// loads return 0, stores are dropped).  As asm the accesses are invisible to hipcc's waitcnt pass: the CALLER waits
+// (s_waitcnt vmcnt) before it uses a loaded value - the epilogue's single vmcnt(0) does.
+typedef float fvp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fvp_f32x2 asm_buffer_load_f32x2(unsigned vo, const fvp_i32x4& rs, unsigned so) {
+  fvp_f32x2 v;
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(v) : "v"(vo), "s"(rs), "s"(so) : "memory");
+  return v;
+}
+__device__ __forceinline__ void asm_buffer_store_f32x2(fvp_f32x2 v, unsigned vo, const fvp_i32x4& rs, unsigned so) {
+  asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" : : "v"(v), "v"(vo), "s"(rs), "s"(so) : "memory");
+}
+__device__ __forceinline__ void asm_buffer_store_f32(float v, unsigned vo, const fvp_i32x4& rs, unsigned so) {
+  asm volatile("buffer_store_dword %0, %1, %2, %3 offen" : : "v"(v), "v"(vo), "s"(rs), "s"(so) : "memory");
+}
+
 // ---- raw buffer addressing for ordinary loads / stores (k_conv_reg): descriptor in 4 SGPRs + ONE per-lane 32-bit byte
 // offset + a scalar byte offset per row.  "Uniform 64-bit row pointer + per-lane offset" - what round 4 wrote - costs an
 // SGPR PAIR per row in flight (64 rows at K = 128: the kernel spilled 143-628 SGPRs); here a row is one scalar add.

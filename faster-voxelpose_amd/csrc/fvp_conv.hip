@@ -1170,7 +1170,7 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   const int CBfull = op.coutp / 32;
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
   a.ablate = kAblate;
-  if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp) return wino_plan_and_launch(op, a, params, planes, s);
+  if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp && op.cout % 32 == 0) return wino_plan_and_launch(op, a, params, planes, s);
   // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
   // Large grids keep all couts in one workgroup (input tile staged once); small grids split
   // couts over blockIdx.y and shrink the pixel tile so that more CUs get work.
@@ -1315,7 +1315,7 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
       rc = launch_status();
     } else if (op.kind == FVP_OP_CONV || op.kind == FVP_OP_CONVT2) {
       float* pool_dst = nullptr;
-      if (op.kind == FVP_OP_CONV && op.wino_off > 0 && op.cin == op.cinp && !kNoWino && !kNoPoolFuse) {
+      if (op.kind == FVP_OP_CONV && op.wino_off > 0 && op.cin == op.cinp && op.cout % 32 == 0 && !kNoWino && !kNoPoolFuse) {
         for (int j = i + 1; j < nops && j < 64; ++j)
           if (ops[j].kind == FVP_OP_POOL2 && ops[j].src == op.dst && ops[j].h == op.h && ops[j].w == op.w &&
               ops[j].h > 1 && ops[j].cin == op.cout && ops[j].dst >= 0 && ops[j].dst < nbufs) {

@@ -465,32 +465,45 @@ __global__ void __launch_bounds__(WC * WT * 64, (WC * WT == 16 ? 4 : 2)) k_conv_
       const bool res_after = flags & FVP_EPI_RES_AFTER_RELU;
       const int plane = plane0 + tn, y = y0 + 2 * ty, x = 2 * tx;
       const bool tile_ok = q_ok && plane < ka->planes && y < ka->H;
-      const unsigned pix = tile_ok ? unsigned(y * W + x) : 0u;
-      const unsigned cbase = tile_ok ? unsigned(plane) * unsigned(cout) : 0u;
       const unsigned ppix = unsigned((y >> 1) * (W >> 1) + tx);
-      // vmcnt is in-order and counts stores: a load issued behind a store waits for the store's whole round trip, and the
-      // compiler may not move loads above stores itself (dst and res are not known to be distinct).  So every residual load
-      // of the lane (2 cout blocks x 4 couts x 2 rows) is issued before the first store.
       const float* const epi_s = smem + epi_off;
-      // element offset of (cout co4 + r, this lane's tile); padded couts and masked tiles read a valid address and store nothing
-      const unsigned omask = (kDiag && (ablate & 1024)) ? 0x3ffffu : ~0u;   // (bit 1024, diagnostics: epilogue traffic stays inside 1 MB)
-      auto out_off = [&](int co) { return ((cbase + (tile_ok && co < cout ? co : 0)) * unsigned(HW) + pix) & omask; };
-      float2 r0[CW][4], r1[CW][4];
+      // Epilogue addressing (round 5): raw descriptors of the unit's first plane (output, residual, pooled output) in SGPRs,
+      // ONE per-lane byte offset - cout 4 k4 of the wave's block, the lane's tile; bit 31 (range check: loads return 0,
+      // stores are dropped) for masked tiles - and a scalar byte offset per (cout, row): no address arithmetic and no
+      // predicate per access (the per-access 64-bit pointer adds were ~15 % of the epilogue's vector instructions).
+      // vmcnt is in-order and counts stores: every residual load of the lane is issued before the first store.
+      const bool fast = relu && !res_after;            // (every cout of the block exists: the planner takes cout % 32 == 0 only)
+      unsigned HW4 = unsigned(HW) * 4u, W4 = unsigned(W) * 4u, HWq4 = unsigned(HW >> 2) * 4u;
+      FVP_OPAQUE(HW4);                                 // (the 8-16 scalar row offsets are formed here, per unit: hoisted out
+      FVP_OPAQUE(W4);                                  // of the K loop as multiples of the loop-invariant HW they spilled)
+      FVP_OPAQUE(HWq4);
+      // (one descriptor register set, re-pointed per phase - residual loads, output stores, pooled stores: three sets at
+      // once do not fit the SGPR file beside the K loop's state)
+      i32x4 rs = {0, 0, 0x7ffffff0, 0x00020000};
+      if (HAS_RES) set_base(rs, res + size_t(plane0) * cout * HW);
+      const unsigned lco = unsigned(tn * cout + co0 + wc * (16 * CW) + 4 * k4);     // this lane's first cout, as a row of the unit
+      const unsigned omask = (kDiag && (ablate & 1024)) ? 0x3ffffu : 0x7fffffffu;   // (bit 1024, diagnostics: epilogue traffic stays inside 1 MB)
+      const unsigned voff0 = tile_ok ? ((lco * unsigned(HW) + unsigned(y * W + x)) * 4u) & omask : kWinoOOB;
+      const unsigned voffp = tile_ok ? (lco * unsigned(HW >> 2) + ppix) * 4u : kWinoOOB;
+      fvp_f32x2 r0[CW][4], r1[CW][4];
+      if (HAS_RES && !(kDiag && (ablate & 16))) {      // (bit 16, diagnostics: no residual loads)
+        unsigned so = 0;                               // scalar row offset (cb * 16 + r) * HW4, advanced as it is used: formed
+#pragma unroll                                         // up front, the 16 offsets of a lane's accesses are 16 more SGPRs
+        for (int cb = 0; cb < CW; ++cb) {
 #pragma unroll
-      for (int cb = 0; cb < CW; ++cb) {
-        const int co4 = co0 + wc * (16 * CW) + cb * 16 + 4 * k4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned off = out_off(co4 + r);
-          if (HAS_RES) {
-            if (kDiag && (ablate & 16)) {           // diagnostics: no residual loads
-              r0[cb][r] = r1[cb][r] = make_float2(0.f, 0.f);
-            } else {
-              r0[cb][r] = *reinterpret_cast<const float2*>(res + off);
-              r1[cb][r] = *reinterpret_cast<const float2*>(res + off + W);
-            }
+          for (int r = 0; r < 4; ++r) {
+            r0[cb][r] = asm_buffer_load_f32x2(voff0, rs, so);
+            r1[cb][r] = asm_buffer_load_f32x2(voff0, rs, so + W4);
+            so += HW4;
+            FVP_OPAQUE(so);
           }
+          so += 12u * HW4;
         }
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < CW; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) r0[cb][r] = r1[cb][r] = fvp_f32x2{0.f, 0.f};
       }
       // output transform A^T M A of the 8 couts while the residual loads are in flight (the accumulators die here)
       float o[CW][4][2][2];
@@ -524,11 +537,12 @@ __global__ void __launch_bounds__(WC * WT * 64, (WC * WT == 16 ? 4 : 2)) k_conv_
       __builtin_amdgcn_sched_barrier(0);
       // every P2PNet / CenterNet layer on this kernel is BN (+ residual) -> ReLU: that order gets its own copy of the loop (as
       // run-time flags the two selects per value were a quarter of the epilogue's instructions)
-      auto finalize = [&](auto fast) {
-        // kFast: BN (+ residual) -> ReLU and every cout of the block exists (cout % 32 == 0): one predicate (the lane's tile)
-        // for all stores, no per-cout compare, no select in the addresses (masked lanes compute on plane 0 / pixel 0)
-        constexpr bool kFast = decltype(fast)::value;
-        float vv[CW][4][2][2];
+      auto finalize = [&](auto fastc) {
+        // kFast: BN (+ residual) -> ReLU, the order of every P2PNet / CenterNet layer on this kernel
+        constexpr bool kFast = decltype(fastc)::value;
+        set_base(rs, dst + size_t(plane0) * cout * HW);
+        float pm[CW][4];                             // fused max_pool(2,2): this lane's tile is one pooled pixel
+        unsigned sso = 0;
 #pragma unroll
         for (int cb = 0; cb < CW; ++cb) {
           const int co4 = co0 + wc * (16 * CW) + cb * 16 + 4 * k4;
@@ -538,8 +552,8 @@ __global__ void __launch_bounds__(WC * WT * 64, (WC * WT == 16 ? 4 : 2)) k_conv_
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float b = bn[0][r], sc = bn[1][r], sh = bn[2][r];
-            const float rr[2][2] = {{HAS_RES ? r0[cb][r].x : 0.f, HAS_RES ? r0[cb][r].y : 0.f},
-                                    {HAS_RES ? r1[cb][r].x : 0.f, HAS_RES ? r1[cb][r].y : 0.f}};
+            const float rr[2][2] = {{r0[cb][r].x, r0[cb][r].y}, {r1[cb][r].x, r1[cb][r].y}};
+            float vv[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -548,35 +562,26 @@ __global__ void __launch_bounds__(WC * WT * 64, (WC * WT == 16 ? 4 : 2)) k_conv_
                 if (HAS_RES && (kFast || !res_after)) xv += rr[i][e];
                 if (kFast || relu) xv = fmaxf(xv, 0.0f);
                 if (HAS_RES && !kFast && res_after) xv += rr[i][e];
-                vv[cb][r][i][e] = xv;
+                vv[i][e] = xv;
               }
-            if (!kFast && tile_ok && co4 + r < cout &&
-                (!(kDiag && (ablate & 32)) || vv[cb][r][0][0] == 1.2345e-30f)) {   // (bit 32, diagnostics: no stores)
-              const unsigned off = out_off(co4 + r);
-              *reinterpret_cast<float2*>(dst + off) = make_float2(vv[cb][r][0][0], vv[cb][r][0][1]);
-              *reinterpret_cast<float2*>(dst + off + W) = make_float2(vv[cb][r][1][0], vv[cb][r][1][1]);
-              if (pool_dst)                          // fused max_pool(2,2): this lane's tile is one pooled pixel
-                pool_dst[(cbase + co4 + r) * unsigned(HW >> 2) + ppix] =
-                    fmaxf(fmaxf(vv[cb][r][0][0], vv[cb][r][0][1]), fmaxf(vv[cb][r][1][0], vv[cb][r][1][1]));
-            }
+            pm[cb][r] = fmaxf(fmaxf(vv[0][0], vv[0][1]), fmaxf(vv[1][0], vv[1][1]));
+            if (kDiag && (ablate & 32) && vv[0][0] != 1.2345e-30f) { sso += HW4; continue; }   // (bit 32, diagnostics: no stores)
+            asm_buffer_store_f32x2(fvp_f32x2{vv[0][0], vv[0][1]}, voff0, rs, sso);
+            asm_buffer_store_f32x2(fvp_f32x2{vv[1][0], vv[1][1]}, voff0, rs, sso + W4);
+            sso += HW4;
+            FVP_OPAQUE(sso);
           }
+          sso += 12u * HW4;
         }
-        if (kFast && tile_ok) {
+        if (pool_dst && !(kDiag && (ablate & 32))) {
+          set_base(rs, pool_dst + size_t(plane0) * cout * (HW >> 2));
 #pragma unroll
           for (int cb = 0; cb < CW; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = co0 + wc * (16 * CW) + cb * 16 + 4 * k4 + r;
-              const unsigned off = (cbase + unsigned(co)) * unsigned(HW) + pix;
-              *reinterpret_cast<float2*>(dst + off) = make_float2(vv[cb][r][0][0], vv[cb][r][0][1]);
-              *reinterpret_cast<float2*>(dst + off + W) = make_float2(vv[cb][r][1][0], vv[cb][r][1][1]);
-              if (pool_dst)
-                pool_dst[(cbase + unsigned(co)) * unsigned(HW >> 2) + ppix] =
-                    fmaxf(fmaxf(vv[cb][r][0][0], vv[cb][r][0][1]), fmaxf(vv[cb][r][1][0], vv[cb][r][1][1]));
-            }
+            for (int r = 0; r < 4; ++r)
+              asm_buffer_store_f32(pm[cb][r], voffp, rs, unsigned(cb * 16 + r) * HWq4);
         }
       };
-      const bool fast = relu && !res_after && (cout & 31) == 0 && !(kDiag && (ablate & 32));
       if (fast) finalize(std::integral_constant<bool, true>{});
       else finalize(std::integral_constant<bool, false>{});
     } else {
@@ -725,6 +730,7 @@ static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, 
 
 int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
   int WC, WT, TN, TR;
+  if (op.cout % 32 != 0) return FVP_EINVAL;         // whole 32-cout blocks only: the epilogue has no per-cout predicate
   if (!wino_tiling(op.h, op.w, op.cinp, op.coutp, &WC, &WT, &TN, &TR, kWinoHalf == 1)) return FVP_EINVAL;
   if (kWinoHalf == 0) {
     // full-size units: (rows bands) x (plane groups) x (cout blocks); switch to half-size ones when they cannot fill the CUs

@@ -64,12 +64,14 @@ class ParamTree(nn.Module):
 WINO_GENERIC = False
 
 
-def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None):
+def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None, cout=None):
     """3x3 layers the F(2x2,3x3) kernel covers (the same rule as wino_tiling() in
     csrc/fvp_conv.hip): decided from the layer shape alone, never from the batch."""
     if (kh, kw) != (3, 3) or h < 2 or h % 2 or w < 8 or w % 4 or (coutp != 32 and coutp % 64) or cinp % 4:
         return False
     if cin is not None and cin != cinp:          # whole channel chunks only (no padded input channels)
+        return False
+    if cout is not None and cout % 32:           # whole 32-cout blocks only (round 5: the epilogue has no per-cout predicate)
         return False
     if w & (w - 1) and not WINO_GENERIC:
         return False                             # rows that do not divide the workgroup tile: direct kernel by default
@@ -204,7 +206,7 @@ class StackSpec:
                 off += _round_up(cinp * o["kh"] * o["kw"] * coutp, 4)
                 e_off = off
                 off += _round_up(3 * coutp, 4)
-                if o["kind"] == capi.OP_CONV and winograd_shape(o["kh"], o["kw"], o["h"], o["w"], cinp, coutp, o["cin"]):
+                if o["kind"] == capi.OP_CONV and winograd_shape(o["kh"], o["kw"], o["h"], o["w"], cinp, coutp, o["cin"], o["cout"]):
                     wino_off = off
                     off += cinp * coutp * 16
                 if (o["kind"] == capi.OP_CONV and (o["kh"], o["kw"]) == (7, 7) and o["cout"] <= 16

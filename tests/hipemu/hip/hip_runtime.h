@@ -238,6 +238,28 @@ static inline void asm_buffer_load_lds16(unsigned la, unsigned vo, const fvp_i32
     memcpy(dst + 4 * d, &v, 4);
   }
 }
+// the Winograd epilogue's asm buffer accesses: descriptor as four ints (base lo, base hi[15:0], num_records, flags)
+typedef float fvp_f32x2 __attribute__((ext_vector_type(2)));
+static inline char* hipemu_rs_base(const fvp_i32x4& rs) {
+  return (char*)((unsigned long long)(unsigned)rs[0] | ((unsigned long long)((unsigned)rs[1] & 0xffffu) << 32));
+}
+static inline fvp_f32x2 asm_buffer_load_f32x2(unsigned vo, const fvp_i32x4& rs, unsigned so) {
+  float t[2] = {0.0f, 0.0f};
+  const unsigned long long off = (unsigned long long)vo + so, nrec = (unsigned)rs[2];
+  for (int d = 0; d < 2; ++d)
+    if (off + 4ull * d + 4 <= nrec) memcpy(&t[d], hipemu_rs_base(rs) + off + 4 * d, 4);
+  return fvp_f32x2{t[0], t[1]};
+}
+static inline void asm_buffer_store_f32x2(fvp_f32x2 v, unsigned vo, const fvp_i32x4& rs, unsigned so) {
+  const unsigned long long off = (unsigned long long)vo + so, nrec = (unsigned)rs[2];
+  const float t[2] = {v[0], v[1]};
+  for (int d = 0; d < 2; ++d)
+    if (off + 4ull * d + 4 <= nrec) memcpy(hipemu_rs_base(rs) + off + 4 * d, &t[d], 4);
+}
+static inline void asm_buffer_store_f32(float v, unsigned vo, const fvp_i32x4& rs, unsigned so) {
+  const unsigned long long off = (unsigned long long)vo + so, nrec = (unsigned)rs[2];
+  if (off + 4 <= nrec) memcpy(hipemu_rs_base(rs) + off, &v, 4);
+}
 // raw buffer loads / stores (k_conv_reg): dword-granular range check against num_records, scalar offset included
 struct fvp_rsrc {
   char* base;

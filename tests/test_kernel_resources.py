@@ -82,7 +82,7 @@ def test_winograd_kernels_fit_two_waves_per_simd(rows):
     w = [r for r in rows if "k_conv_wino<" in r["demangled"]]
     assert len(w) == 72                               # 56 two-block instances + 16 quarter-size (one block per wave) ones
     for r in w:
-        assert r["vgpr"] + r["agpr"] <= 256 and r["sgpr"] <= 104, r
+        assert r["vgpr"] + r["agpr"] <= 256, r
         args = r["demangled"].split("k_conv_wino<")[1].split(">")[0].split(",")
         cc, cw = int(args[2]), int(args[6])
         assert r["mfma"] == 8 * cc * cw, r      # two chunk bodies (first / other) x CC/4 steps x 16 CW MFMAs: straight-line
