@@ -650,6 +650,9 @@ def main():
                 if args.config != "panoptic128":
                     other["panoptic128 (BASELINE configs[3]): 128x128x32, jln128, one frame per GPU (B = 1)"] = \
                         secondary_leg("panoptic128", 1, args.streams, 20, 3, dev)
+                if B != 32:
+                    other[f"{args.config}, B = 32 per step (same shape, larger batch: parity = the sweep_panoptic_b32 leg)"] = \
+                        secondary_leg(args.config, 32, args.streams, 10, 2, dev)
                 if args.config != "campus":
                     other["campus (BASELINE configs[0] shape): 3 views, J = 17, 80x80x20, jln64, B = 8"] = \
                         secondary_leg("campus", 8, args.streams, 20, 3, dev)
