@@ -29,14 +29,17 @@
 //     body is straight-line code and every counted wait is an immediate;
 //   * the per-unit part of a DMA item is 'inside the image or not' only: the lane's byte offset relative to the unit's
 //     descriptor base never changes, the validity is bit 31 of that offset (fails the buffer range check -> the
-//     hardware writes zeros), recomputed per unit from an 8+8-bit (row, plane) tag with ~8 vector instructions per item
-//     and no exec-mask branches;
+//     hardware writes zeros), recomputed per unit from the lane number (a dozen vector instructions per item, no
+//     exec-mask branches, nothing kept in registers for it);
 //   * arguments that only the epilogue or the cursor needs are re-read from the kernarg segment where they are used
 //     (fresh_args) instead of living in SGPRs across the K loop;
 //   * the validity flags of the plane groups (persons) are staged in LDS: the cursor's look-ahead no longer issues a
 //     global load (vmcnt) in the middle of the DMA ring;
 //   * both chunks staged by the prologue are waited for before the first barrier, so the first chunk barrier of EVERY
-//     unit needs no vmcnt wait (the epilogue's single vmcnt(0) covers it, see there).
+//     unit needs no vmcnt wait (the epilogue's single vmcnt(0) covers it, see there);
+//   * the epilogue's residual loads / stores are raw-buffer accesses (one per-lane offset + a running scalar row offset);
+//   * CW = 1 forms (one 16-cout block per wave): quarter-size units for launches that cannot fill the chip (B = 1), and -
+//     diagnostics build only, measured 10-20 % slower - the 16-wave / four-waves-per-SIMD form.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__(WC * WT * 64, (WC * WT == 16 ? 4 : 2)) k_conv_
   // instruction per chunk.  The item's (row, plane) is recomputed from the lane number when the cursor enters a unit
   // (a dozen vector instructions per item and unit) rather than kept in a register.
   unsigned voff[NI];
-  // (row in band, plane in group) of input item j of this lane, or row 511 = never inside (fails the row test for H <= 510)
+  // (row in band, plane in group) of input item j of this lane and whether the item can lie inside the image at all
   auto item_pos = [&](int j, int& ry, int& n, bool& inside, int& ci, int& qd) {
     const int qpr = (W >> 2) + 1;
     const int rows_per_ch = a.TN * THp;
@@ -779,8 +782,6 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   a.m_tpr = make_magic(a.tpr);
   a.vec = a.dma = 1;
   a.zeros = params;
-  // the tag of a DMA item holds its row in the band in 9 bits (511 = never inside) and its plane in the group in 7
-  if (a.TH + 2 > 510 || op.h > 510 || TN > 127) return FVP_ELIMIT;
   const int CBW = 16 * CW * WC;
   // channels per chunk: 8 when it divides cinp and three slots fit, else 4
   // resident weights: one 32-cout block covers all couts and [cinp][32][16] fits beside the three input slots
