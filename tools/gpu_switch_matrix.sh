@@ -15,3 +15,7 @@ run FVP_CONV_NO_WINO=1
 run FVP_CONV_NO_REG=1
 run FVP_CONV_REG_MIN_TILES=1
 run FVP_WINO_HALF=1
+run FVP_WINO_HALF=2
+run FVP_WINO_QUARTER=2
+run FVP_WINO_QUARTER=0
+run FVP_WINO_W16=1 FVP_WINO_HALF=2
