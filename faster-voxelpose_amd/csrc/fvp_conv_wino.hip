@@ -814,6 +814,8 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   a.CC = CC;
   a.wino_ni = ni;
   if (!buf_dma_range_ok(TN, op.cin, op.h, op.w, double(op.cinp) * op.coutp * 16)) return FVP_ELIMIT;
+  // the epilogue's per-lane byte offset spans the unit's TN planes of the output (bit 31 is the 'masked' flag)
+  if ((double(TN) + 1.0) * op.cout * op.h * op.w * 4.0 >= 2147483648.0) return FVP_ELIMIT;
   a.m_qpr = make_magic(op.w / 4 + 1);
   a.m_rpc = make_magic(TN * (a.TH + 2));
   a.m_thp = make_magic(a.TH + 2);
