@@ -1039,6 +1039,9 @@ static int plan_and_launch_reg(const FvpConvOp& op, ConvArgs a, const float* par
   // instances exist for these (cinp, NB, mode) only; the key is injective on that domain (cinp = 56,
   // coutp = 2688 used to alias 6440)
   if (NB < 1 || NB > 4 || (op.cinp != 16 && op.cinp != 32 && op.cinp != 64 && op.cinp != 128)) return -1;
+  // raw-buffer addressing: a plane's input (K rows) and output (cout rows, + 4 for the upper half wave) are addressed with
+  // 32-bit byte offsets and an `int` num_records
+  if (double(op.cinp) * hw * 4.0 >= 2147483648.0 || (double(op.coutp) + 4.0) * hw * (tr ? 4.0 : 1.0) * 4.0 >= 2147483648.0) return -1;
   const int key = op.cinp * 100 + NB * 10 + mode;
   if (key != 1610 && key != 3210 && key != 3220 && key != 6440 && key != 12841 && key != 6421 && key != 6422) return -1;
   a.m_tpp = make_magic(hw / 32);
