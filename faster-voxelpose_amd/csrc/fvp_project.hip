@@ -863,30 +863,42 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   }
   // JP = 16 (Panoptic): the compact-block form WITHOUT LDS staging (k_project_triplane_blk, round 4).  FVP_TRIPLANE_STAGED=1
   // (diagnostics build) keeps the staged quad form for comparison; both give the same bits.
-  if (!gather && nvl == 2 && !quad_form && !staged) {
+  if (!gather && nvl <= 2 && !quad_form && !staged && (nvl == 2 || g->JP == 16)) {
     const int nbx2 = ceil_div(C, kBlkBX);
-    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * 16) * (g->JP + 1) * 4;   // cell pitch JP + 1
-    if (fine_grid)
-      hipLaunchKernelGGL((k_project_triplane_blk<2, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
-                         reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
-                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
-    else
-      hipLaunchKernelGGL((k_project_triplane_blk<2, false>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
-                         reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
-                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
-    return launch_status();
+    const int bz = nvl == 2 ? 16 : kBlkBZ;
+    // z-resident cells (ZRES, diagnostics build only: FVP_TRI_ZRES=1).  Measured in round 5, same box, same bits: Panoptic
+    // 345 -> 389 us, Shelf 587 -> 654 us, Campus 155 -> 187 us.  The 35-43 KB of cells per workgroup cap a CU at 3-4
+    // workgroups where the per-z-block cells (10 KB) let the register count decide (5), and the barriers it removes were
+    // never the bound: the phases of the other workgroups on the CU already fill them.
+    int zsh = 0;
+    while ((1 << zsh) < C) ++zsh;
+    const size_t lds_z = (size_t(kBlkBX + kBY) << zsh) * (g->JP + 1) * 4;
+#if FVP_DIAG
+    const char* zr_env = fvp::diag_env("FVP_TRI_ZRES");
+    const bool zres = zr_env && atoi(zr_env) != 0 && (1 << zsh) >= bz && lds_z <= kTriZresMaxLds;
+#else
+    constexpr bool zres = false;
+#endif
+    const size_t lds_b = zres ? lds_z : size_t(kBlkBX * kBY + (kBlkBX + kBY) * bz) * (g->JP + 1) * 4;   // cell pitch JP + 1
+#define CALLB(NVL_, CACHED_, ZRES_)                                                                                          \
+  hipLaunchKernelGGL((k_project_triplane_blk<NVL_, CACHED_, ZRES_>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b,       \
+                     as_stream(s), heat_cl, reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, \
+                     fx, fy, fz, C, nP, nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes, zsh)
+#if FVP_DIAG
+#define CALLB2(NVL_)                                                                     \
+  {                                                                                      \
+    if (fine_grid) { if (zres) CALLB(NVL_, true, true); else CALLB(NVL_, true, false); } \
+    else { if (zres) CALLB(NVL_, false, true); else CALLB(NVL_, false, false); }         \
   }
-  if (!gather && nvl == 1 && !quad_form && !staged && g->JP == 16) {
-    const int nbx2 = ceil_div(C, kBlkBX);
-    const size_t lds_b = size_t(kBlkBX * kBY + (kBlkBX + kBY) * kBlkBZ) * (g->JP + 1) * 4;   // cell pitch JP + 1
-    if (fine_grid)
-      hipLaunchKernelGGL((k_project_triplane_blk<1, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
-                         reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
-                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
-    else
-      hipLaunchKernelGGL((k_project_triplane_blk<1, false>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s), heat_cl,
-                         reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
-                         nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes);
+#else
+#define CALLB2(NVL_)                                                                     \
+  {                                                                                      \
+    if (fine_grid) CALLB(NVL_, true, false); else CALLB(NVL_, false, false);             \
+  }
+#endif
+    if (nvl == 2) CALLB2(2) else CALLB2(1)
+#undef CALLB2
+#undef CALLB
     return launch_status();
   }
   if (!gather && nvl <= 2) {

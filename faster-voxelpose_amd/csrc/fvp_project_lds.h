@@ -472,13 +472,21 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
 #endif
 constexpr int kBlkBX = FVP_TRI_BLK_BX, kBlkBZ = FVP_TRI_BLK_BZ;
 constexpr int kBlkThreads = kBlkBX * kBY * 4 * 4;
-template <int NVL, bool CACHED>
+#ifndef FVP_TRI_ZRES_MAX_KB
+#define FVP_TRI_ZRES_MAX_KB 48
+#endif
+constexpr size_t kTriZresMaxLds = size_t(FVP_TRI_ZRES_MAX_KB) * 1024;   // z-resident plane cells per workgroup (ZRES form)
+// ZRES (round 5): the x-z / y-z cells of the workgroup's WHOLE z range (2^zsh >= C cells per row) stay in LDS across its
+// z blocks and the x-y maxima stay in registers (the same lane owns a column in every z block): one zero fill, no barrier
+// inside the z loop, one merge into the global planes at the end - instead of zero fill + 3 barriers + merge per z block.
+// max is order-independent: same bits.
+template <int NVL, bool CACHED, bool ZRES>
 __global__ void __launch_bounds__(kBlkThreads, FVP_TRI_BLK_OCC)
 k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
                        const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
                        const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
                        const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, FvpGeom g,
-                       const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes) {
+                       const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes, int zsh) {
   constexpr int BZ = NVL == 1 ? kBlkBZ : 16;
   constexpr int VPT = BZ / 4;
   constexpr int OWN = VPT / 4;
@@ -527,6 +535,19 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
   float* pxz = planes + (size_t(p) * 3 + 1) * J * CC;
   float* pyz = planes + (size_t(p) * 3 + 2) * J * CC;
   const float nv = float(V);
+  const int JPp = JP + 1;                                                // cell pitch (see below)
+  [[maybe_unused]] int mxy[NVL][4];                                      // ZRES: running x-y maxima of this lane's column
+  [[maybe_unused]] const int zt = 1 << zsh;
+  if constexpr (ZRES) {
+#pragma unroll
+    for (int n = 0; n < NVL; ++n)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mxy[n][c] = 0;
+    int* cz = reinterpret_cast<int*>(smem);                              // [kBX + kBY rows][zt][JPp]
+    const int ncell = ((kBX + kBY) << zsh) * JPp;
+    for (int i = t; i < ncell; i += NT) cz[i] = 0;
+    __syncthreads();
+  }
 
   for (int gz0 = s2; gz0 < e2; gz0 += BZ) {
     float acc[VPT][NVL][4];
@@ -619,7 +640,33 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
     // y pairs of a 32-lane group share them): SQ_LDS_BANK_CONFLICT was 7.6 cycles per LDS instruction of this kernel.
     // With the odd pitch the 32 lanes of a group hit 32 different banks; only the same-address pairs of the x-z cells
     // (the two y lanes of a group) still serialise.
-    const int JPp = JP + 1;
+    if constexpr (ZRES) {
+      int* rxz = reinterpret_cast<int*>(smem);                           // [kBX][zt][JPp]
+      int* ryz = rxz + ((kBX << zsh) * JPp);                             // [kBY][zt][JPp]
+      const int zb = gz0 - s2 + zs;
+#pragma unroll
+      for (int n = 0; n < NVL; ++n)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ch = 16 * n + 4 * q + c;
+          float mz = 0.0f;
+#pragma unroll
+          for (int i = 0; i < VPT; ++i) {
+            const float val = fmaxf(acc[i][n][c], 0.0f);
+            mz = fmaxf(mz, val);
+            if (val > 0.0f && ch < JP) {
+              const int z = zb + 4 * i;
+              atomicMax(&rxz[((xx << zsh) + z) * JPp + ch], __float_as_int(val));
+              atomicMax(&ryz[((yy << zsh) + z) * JPp + ch], __float_as_int(val));
+            }
+          }
+          int mi = __float_as_int(mz);
+          mi = imax(mi, dpp_i<0x124>(mi));
+          mi = imax(mi, dpp_i<0x128>(mi));
+          mxy[n][c] = imax(mxy[n][c], mi);
+        }
+      continue;
+    }
     int* cxy = reinterpret_cast<int*>(smem);                             // [kBX * kBY columns][JPp]
     int* cxz = cxy + kBX * kBY * JPp;                                    // [kBX][BZ][JPp]
     int* cyz = cxz + kBX * BZ * JPp;                                     // [kBY][BZ][JPp]
@@ -664,6 +711,39 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
       const int ch = i / ((kBX + kBY) * BZ), r = i - ch * ((kBX + kBY) * BZ), a = r / BZ, z = r - a * BZ;
       if (gz0 + z < e2) {
         const int raw = cxz[r * JPp + ch];
+        const int vv = raw > 0 ? __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f)) : 0;
+        if (vv > 0) {
+          if (a < kBX) {
+            if (gx0 + a < e0) plane_max(&pxz[size_t(ch) * CC + (gx0 + a - tl0) * C + lz0 + z], vv);
+          } else if (gy0 + a - kBX < e1) {
+            plane_max(&pyz[size_t(ch) * CC + (gy0 + a - kBX - tl1) * C + lz0 + z], vv);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (ZRES) {
+    __syncthreads();                                                     // every wave's cell maxima are in
+    if (zs == 0 && col_in) {
+#pragma unroll
+      for (int n = 0; n < NVL; ++n)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ch = 16 * n + 4 * q + c;
+          if (ch < J && mxy[n][c] > 0) {
+            const int vv = __float_as_int(clampf(__fdiv_rn(__int_as_float(mxy[n][c]), nv), 0.0f, 1.0f));
+            if (vv > 0) plane_max(&pxy[size_t(ch) * CC + (gxi - tl0) * C + (gyi - tl1)], vv);
+          }
+        }
+    }
+    const int* cz = reinterpret_cast<const int*>(smem);
+    const int nz = e2 - s2, lz0 = s2 - tl2;
+    const int rows = (kBX + kBY) << zsh;                                 // x-z rows then y-z rows, z fastest
+    for (int i = t; i < rows * J; i += NT) {
+      static_assert(kBX + kBY == 8, "row count is a power of two");
+      const int ch = i >> (zsh + 3), r = i & (rows - 1), a = r >> zsh, z = r & (zt - 1);
+      if (z < nz) {
+        const int raw = cz[r * JPp + ch];
         const int vv = raw > 0 ? __float_as_int(clampf(__fdiv_rn(__int_as_float(raw), nv), 0.0f, 1.0f)) : 0;
         if (vv > 0) {
           if (a < kBX) {

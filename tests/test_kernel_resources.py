@@ -21,7 +21,7 @@ ALTERNATE_FORMS = {
     "k_project_triplane_lds2": (49, 11),      # (max SGPR spills, max VGPR spills)
     "k_project_triplane_lds<": (67, 5),
     "k_project_triplane<": (56, 0),
-    "k_project_triplane_blk<2, false>": (4, 0),
+    "k_project_triplane_blk<2, false, false>": (4, 0),
     # soft-argmax + WeightNet: 24 SGPR spills in the feature loop.  The three spill-free forms tried in round 5 (template
     # on F without the predicates + scalars re-read behind an opaque pointer, per window / per feature group / chained to an
     # earlier feature's result) measured 252-299 us against 177 us per launch: the spills are the faster code.
@@ -53,7 +53,7 @@ def test_library_holds_the_expected_kernels(rows):
     names = " ".join(r["demangled"] for r in rows)
     assert len(rows) >= 150
     for k in ("k_conv_wino<2, 4, 8, 2, true, false, 2>", "k_conv_reg<128, 4, 1, true>", "k_conv_dma<7, 7, 1, 4, true",
-              "k_project_triplane_blk<1, true>", "k_project_whole_q", "k_conv1d_fused", "k_softargmax_weightnet",
+              "k_project_triplane_blk<1, true, false>", "k_project_whole_q", "k_conv1d_fused", "k_softargmax_weightnet",
               "k_bb_conv_dma"):
         assert k in names, k
 
