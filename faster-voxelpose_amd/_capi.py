@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfvp_hip.so"
-ABI_VERSION = 6            # include/fvp.h FVP_ABI_VERSION
+ABI_VERSION = 7            # include/fvp.h FVP_ABI_VERSION
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 FVP_CAM_FLOATS = 24

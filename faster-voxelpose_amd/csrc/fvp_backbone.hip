@@ -975,13 +975,13 @@ extern "C" int fvp_bb_tune(FvpBbOp* ops, int nops, const uint16_t* wblob, const 
       one.flags |= cfg << FVP_BB_CFG_SHIFT;
       rc = fvp_bb_run(&one, 1, wblob, eblob, bufs, nbufs, N, nullptr, 0, nullptr, s);            // warm-up
       if (rc) break;
-      hipEventRecord(e0, st);
+      if (hipEventRecord(e0, st) != hipSuccess) rc = FVP_EINVAL;
       for (int r = 0; r < 3 && !rc; ++r) rc = fvp_bb_run(&one, 1, wblob, eblob, bufs, nbufs, N, nullptr, 0, nullptr, s);
-      hipEventRecord(e1, st);
+      if (hipEventRecord(e1, st) != hipSuccess) rc = FVP_EINVAL;
       if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = FVP_EINVAL;
       if (rc) break;
       float ms = 0.0f;
-      hipEventElapsedTime(&ms, e0, e1);
+      if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = FVP_EINVAL; break; }
       if (best_cfg == 0 || ms < best) {
         best = ms;
         best_cfg = cfg;
@@ -989,7 +989,7 @@ extern "C" int fvp_bb_tune(FvpBbOp* ops, int nops, const uint16_t* wblob, const 
     }
     if (!rc) op.flags |= best_cfg << FVP_BB_CFG_SHIFT;
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return rc;
 }

@@ -906,6 +906,10 @@ k_pack_conv(const float* __restrict__ w, const float* __restrict__ b, const floa
   }
 }
 
+}  // namespace fvp
+#include "fvp_conv7.h"
+namespace fvp {
+
 // PAIR layout of a KHxKW conv with cout <= 16: [cinp][KH][KW+1][32], row co = w[co][ci][ky][kx]
 // (kx < KW), row 16+co = w[co][ci][ky][kx-1] (kx >= 1), zero elsewhere.
 __global__ void __launch_bounds__(256)
@@ -979,6 +983,7 @@ static const int kNoDma = int(env_size("FVP_CONV_NO_DMA", 0));
 
 static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
+static const int kNoK7 = int(env_size("FVP_CONV_NO_K7", 0));        // diagnostics: 7x7 convs on the pixel-pair form of k_conv_dma
 static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const int kNoHeadFuse = int(env_size("FVP_CONV_NO_HEAD_FUSE", 0));
 static const int kNoReg = int(env_size("FVP_CONV_NO_REG", 0));     // diagnostics: 1x1 / transposed convs on k_conv_dma
@@ -1174,6 +1179,32 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
   a.ablate = kAblate;
   if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp && op.cout % 32 == 0) return wino_plan_and_launch(op, a, params, planes, s);
+  // 7x7 front conv on 16x16x4 tiles (k_conv7): a SHAPE rule (map width, channels), never the number of planes.  Maps of
+  // 64 / 128 columns (P2PNet: 30 planes per frame); CenterNet's 80 x 80 map (one plane per frame) stays on the pixel-pair
+  // form - 8 planes: 25.9 us there, 28.9-29.9 us here (160 one-tile workgroups of 784 chained MFMAs per wave).
+  if (!tr && kh == 7 && kw == 7 && op.pair_off > 0 && !kNoK7 && op.cout <= 16 && !(op.flags & FVP_EPI_RES) && !pool_dst && !head &&
+      (op.w == 64 || op.w == 128) && op.cin <= 20 && op.h >= 4) {
+    const int ncg = op.cin <= 16 ? 4 : 5;
+    a.wts = params + op.pair_off + size_t(op.cinp) * 7 * 8 * 32;       // the k-grouped copy behind the pixel-pair copy
+    a.tiles_y = ceil_div(op.h, kK7Rows);
+    const dim3 grid(planes * a.tiles_y);
+    ProfScope ps(FVP_K_CONV, s, 2.0 * op.cin * op.cout * 49.0 * op.h * op.w * planes, 1, prof_level() >= 2);
+#define FVP_K7(W_, NCG_)                                                                                      \
+  {                                                                                                            \
+    static LdsOptIn optin;                                                                                     \
+    auto k = &k_conv7<W_, NCG_>;                                                                               \
+    const size_t lds = size_t(4 * NCG_) * conv7_cs(W_, kK7Rows) * sizeof(float);                               \
+    if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds)) return e;                            \
+    hipLaunchKernelGGL(k, grid, dim3(W_ / 16 * 64), lds, s, a);                                                \
+  }
+    if (ncg == 4) {
+      if (op.w == 64) FVP_K7(64, 4) else FVP_K7(128, 4)
+    } else {
+      if (op.w == 64) FVP_K7(64, 5) else FVP_K7(128, 5)
+    }
+#undef FVP_K7
+    return launch_status();
+  }
   // Accumulator budget: CB*PB = 4 tiles of 32x32 per wave (~141 registers, 3 waves/SIMD).
   // Large grids keep all couts in one workgroup (input tile staged once); small grids split
   // couts over blockIdx.y and shrink the pixel tile so that more CUs get work.
@@ -1368,6 +1399,11 @@ extern "C" int fvp_pack_conv(const float* weight, const float* bias, const float
     FVP_REQUIRE(op->cout <= 16 && op->coutp == 32);
     hipLaunchKernelGGL(k_pack_pair, dim3(ceil_div(op->cinp * op->kh * (op->kw + 1) * 32, 256)), dim3(256), 0,
                        as_stream(s), weight, op->cin, op->cout, op->cinp, op->kh, op->kw, params + op->pair_off);
+    if (op->kh == 7 && op->kw == 7) {                                  // k-grouped copy for k_conv7, behind the pixel-pair copy
+      const int ncg = op->cin <= 16 ? 4 : ceil_div(op->cin, 4);        // (k_conv7 runs four groups for every cin <= 16)
+      hipLaunchKernelGGL(k_pack_k7, dim3(ceil_div(ncg * 49 * 64, 256)), dim3(256), 0, as_stream(s), weight, op->cin, op->cout, ncg,
+                         params + op->pair_off + size_t(op->cinp) * 7 * 8 * 32);
+    }
   }
   if (op->wino_off > 0) {
     FVP_REQUIRE(!transposed && op->kh == 3 && op->kw == 3);

@@ -211,8 +211,10 @@ class StackSpec:
                     off += cinp * coutp * 16
                 if (o["kind"] == capi.OP_CONV and (o["kh"], o["kw"]) == (7, 7) and o["cout"] <= 16
                         and o["w"] % 4 == 0):
-                    pair_off = off                      # pixel-pair layout [cinp][7][8][32]
+                    pair_off = off                      # pixel-pair layout [cinp][7][8][32] ...
                     off += cinp * 7 * 8 * 32
+                    ncg = 4 if o["cin"] <= 16 else -(-o["cin"] // 4)
+                    off += ncg * 49 * 64                # ... + the k-grouped copy [max(4, ceil(cin/4))][49][4][16] (k_conv7)
                 if (o["kind"] == capi.OP_CONVT2 and o["h"] > 1 and o["w"] % 4 == 0 and coutp in (32, 64)):
                     pair_off = off                      # column-tap pairs [dy][cinp][dx*coutp + co]
                     off += 4 * cinp * coutp

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FVP_ABI_VERSION 6
+#define FVP_ABI_VERSION 7
 #define FVP_MAX_VIEWS 8
 #define FVP_CAM_FLOATS 24 /* R[9] T[3] fx fy cx cy k[3] p[2] + 3 pad */
 #define FVP_MAX_JOINTS 32
@@ -171,8 +171,10 @@ typedef struct FvpConvOp {
                               /* conv's weights ([cinp][coutp][16]); when set the conv runs  */
                               /* as F(2x2,3x3) (requires even H, W a power of two)           */
   int32_t pair_off;           /* 0, or float offset of the pixel-pair copy of the weights:    */
-                              /* 7x7 conv with cout <= 16 -> [cinp][7][8][32]; 2-D            */
-                              /* ConvTranspose(k2,s2) -> [dy][cinp][dx*coutp+co] (fvp_conv.hip) */
+                              /* 7x7 conv with cout <= 16 -> [cinp][7][8][32], followed by the */
+                              /* k-grouped copy [max(4, ceil(cin/4))][49][4][16] (ABI 7,       */
+                              /* fvp_conv7.h); 2-D ConvTranspose(k2,s2) ->                     */
+                              /* [dy][cinp][dx*coutp+co] (fvp_conv.hip)                        */
 } FvpConvOp;
 
 /* bufs[i] = device pointer of activation buffer i (caller sized: planes*C*H*W floats).

@@ -227,6 +227,25 @@ def split_k_stack(cin, cmid, hw, seed=0):
     return spec, w, ref, o
 
 
+def front7_stack(cin, hw, seed=0):
+    """The 7x7 front conv of P2PNet / CenterNet (cnns_2d.py:119-121: cin = joints -> 16, BN folded away here, ReLU) on a map
+    whose width k_conv7 takes (64 / 80 / 128): spec, weights, float64 torch reference, output buffer id."""
+    import torch.nn.functional as F
+
+    from faster_voxelpose_amd import netspec
+    spec = netspec.StackSpec(2, cin, hw)
+    spec._conv_entries("f", cin, 16, 7)
+    o = spec.conv("f", None, 0, 16, 7, relu=True)
+    spec.outputs["out"] = o
+    spec.finalize()
+    g = torch.Generator().manual_seed(seed)
+    w = {"f.weight": torch.randn(16, cin, 7, 7, generator=g) / (cin * 49) ** 0.5, "f.bias": torch.randn(16, generator=g) * 0.1}
+
+    def ref(x):
+        return F.relu(F.conv2d(x.double(), w["f.weight"].double(), w["f.bias"].double(), padding=3))
+    return spec, w, ref, o
+
+
 def reg_stack(seed=0, fused_head=True, head_cout=15):
     """1x1 convs and transposed convs with P2PNet's channel counts on 16x16 / 8x8 maps (whole 32-pixel tiles): the layers
     k_conv_reg takes.  x [planes, 32, 16, 16] -> 1x1 32->64, pool, 1x1 64->128, up 128->64 (+ skip), up 64->32 (+ skip),

@@ -13,7 +13,7 @@ import torch
 
 import fvp_oracle as O
 from cases import make_inputs, make_weights
-from common import check_outputs, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
+from common import check_outputs, front7_stack, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
 import fvp_synthetic as S
 from faster_voxelpose_amd.models import faster_voxelpose as FV
 
@@ -258,6 +258,25 @@ def test_split_k_direct_conv_on_small_maps(emu_lib, cin, cmid, hw, planes):
     got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)[o]
     want = ref(x)
     np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,hw,planes", [(15, (10, 64), 3), (17, (8, 64), 2), (3, (4, 128), 1), (15, (8, 80), 2)])
+def test_front_conv7_on_16x16x4_tiles(emu_lib, cin, hw, planes):
+    """k_conv7: the 7x7 front conv with the reduction ordered (channel group of 4, kernel row, kernel column) - widths 64 /
+    128, 15 and 17 joints (4 and 5 channel groups; 15 and 17 are not multiples of 4: zero channels), 3 channels (three
+    all-zero groups), a height that is not a multiple of the 4-row tile, a masked plane; the 80-wide map stays on the
+    pixel-pair form of k_conv_dma.  Against a float64 torch evaluation."""
+    spec, w, ref, o = front7_stack(cin, hw, seed=cin)
+    x = torch.from_numpy(np.random.default_rng(7).normal(size=(planes, cin) + hw).astype(np.float32))
+    got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x)[o]
+    want = ref(x)
+    np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    if planes > 1:
+        valid = torch.ones(planes, dtype=torch.uint8)
+        valid[1] = 0
+        got2 = run_custom_conv_stack(emu_lib, "cpu", spec, w, x, plane_valid=valid)[o]
+        keep = valid.bool()
+        assert torch.equal(got2[keep], got[keep])
 
 
 @pytest.mark.parametrize("fused_head,head_cout", [(True, 15), (False, 15), (True, 17)])

@@ -10,7 +10,7 @@ import torch
 
 import fvp_oracle as O
 from cases import CASES, make_inputs, make_weights
-from common import check_outputs, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
+from common import check_outputs, front7_stack, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
 import fvp_synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -223,6 +223,31 @@ def test_split_k_direct_conv_on_small_maps(cin, cmid, hw, planes):
     np.testing.assert_allclose(got.double().numpy(), ref(x).numpy(), rtol=2e-5, atol=2e-5)
     one = run_custom_conv_stack(lib, DEV, spec, w, x[planes - 1:], st)[o].cpu()
     assert torch.equal(one[0], got[planes - 1])
+
+
+@pytest.mark.parametrize("cin,hw,planes", [(15, (64, 64), 240), (15, (80, 80), 8), (17, (64, 64), 31), (17, (80, 80), 3),
+                                           (15, (10, 64), 3), (15, (128, 128), 5), (3, (4, 128), 1)])
+def test_front_conv7_on_16x16x4_tiles(cin, hw, planes):
+    """The 7x7 front conv of P2PNet / CenterNet at the BASELINE shapes (240 planes of 64x64, 8 of 80x80; 15 and 17 joints),
+    heights that do not divide the 4-row tile, 128-wide maps.  Maps of 64 / 128 columns run k_conv7 (reduction ordered
+    channel group / kernel row / kernel column on 16x16x4 tiles), 80 columns the pixel-pair form of k_conv_dma.  Against a
+    float64 torch evaluation; a plane's bits do not depend on the number of planes in the launch nor on masked neighbours
+    (the form is chosen from the layer shape only)."""
+    from faster_voxelpose_amd import _capi as capi
+    lib = capi.load()
+    spec, w, ref, o = front7_stack(cin, hw, seed=cin)
+    x = torch.from_numpy(np.random.default_rng(7).normal(size=(planes, cin) + hw).astype(np.float32))
+    st = torch.cuda.current_stream().cuda_stream
+    got = run_custom_conv_stack(lib, DEV, spec, w, x, st)[o].cpu()
+    n = min(planes, 6)
+    np.testing.assert_allclose(got[:n].double().numpy(), ref(x[:n]).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got[-1:].double().numpy(), ref(x[-1:]).numpy(), rtol=2e-5, atol=2e-5)
+    one = run_custom_conv_stack(lib, DEV, spec, w, x[planes - 1:], st)[o].cpu()
+    assert torch.equal(one[0], got[planes - 1])
+    if planes > 2:
+        valid = (torch.arange(planes) % 3 != 1).to(torch.uint8)
+        masked = run_custom_conv_stack(lib, DEV, spec, w, x, st, plane_valid=valid)[o].cpu()
+        assert torch.equal(masked[valid.bool()], got[valid.bool()])
 
 
 @pytest.mark.parametrize("fused_head,head_cout", [(True, 15), (False, 15), (True, 17)])

@@ -20,3 +20,4 @@ run FVP_WINO_QUARTER=2
 run FVP_WINO_QUARTER=0
 run FVP_WINO_W16=1 FVP_WINO_HALF=2
 run FVP_TRI_ZRES=1
+run FVP_CONV_NO_K7=1
