@@ -984,6 +984,7 @@ static const int kNoDma = int(env_size("FVP_CONV_NO_DMA", 0));
 static const int kNoWino = int(env_size("FVP_CONV_NO_WINO", 0));
 static const int kNoPair = int(env_size("FVP_CONV_NO_PAIR", 0));
 static const int kNoK7 = int(env_size("FVP_CONV_NO_K7", 0));        // diagnostics: 7x7 convs on the pixel-pair form of k_conv_dma
+static const size_t kK7LdsPad = env_size("FVP_K7_LDS_KB", 0) * 1024;  // diagnostics: pad k_conv7's LDS request (fewer workgroups per CU)
 static const int kNoPoolFuse = int(env_size("FVP_CONV_NO_POOL_FUSE", 0));
 static const int kNoHeadFuse = int(env_size("FVP_CONV_NO_HEAD_FUSE", 0));
 static const int kNoReg = int(env_size("FVP_CONV_NO_REG", 0));     // diagnostics: 1x1 / transposed convs on k_conv_dma
@@ -1193,7 +1194,7 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   {                                                                                                            \
     static LdsOptIn optin;                                                                                     \
     auto k = &k_conv7<W_, NCG_>;                                                                               \
-    const size_t lds = size_t(4 * NCG_) * conv7_cs(W_, kK7Rows) * sizeof(float);                               \
+    const size_t lds = std::max(kK7LdsPad, size_t(4 * NCG_) * conv7_cs(W_, kK7Rows) * sizeof(float));          \
     if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds)) return e;                            \
     hipLaunchKernelGGL(k, grid, dim3(W_ / 16 * 64), lds, s, a);                                                \
   }

@@ -36,12 +36,15 @@ constexpr int conv7_cs(int W, int R) {                 // words between channel 
 #define FVP_K7_R 4                                     // output rows per tile (and per wave)
 #endif
 constexpr int kK7Rows = FVP_K7_R;
+#ifndef FVP_K7_OCC
+#define FVP_K7_OCC 3                                    // waves per SIMD the four-group instances are compiled for
+#endif
 #ifndef FVP_K7_ABLATE
 #define FVP_K7_ABLATE 0                                // variant builds only (wrong results): 1 no tile DMA, 2 no LDS reads, 4 no weight loads
 #endif
 
 template <int W, int NCG, int R = kK7Rows>
-__global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? 3 : 2) k_conv7(ConvArgs a) {
+__global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? FVP_K7_OCC : 2) k_conv7(ConvArgs a) {
   HIP_DYNAMIC_SHARED(float, smem)
   constexpr int NW = W / 16, NT = NW * 64;
   constexpr int THp = R + 6, WP = W + 4, QPR = WP / 4;
