@@ -54,7 +54,7 @@ def test_library_holds_the_expected_kernels(rows):
     assert len(rows) >= 150
     for k in ("k_conv_wino<2, 4, 8, 2, true, false, 2>", "k_conv_reg<128, 4, 1, true>", "k_conv_dma<7, 7, 1, 4, true",
               "k_project_triplane_blk<1, true, false>", "k_project_whole_q", "k_conv1d_fused", "k_softargmax_weightnet",
-              "k_bb_conv_dma"):
+              "k_bb_conv_dma", "k_conv7<64, 4, 4>", "k_conv7<64, 5, 4>", "k_conv7<128, 4, 4>"):
         assert k in names, k
 
 
@@ -86,3 +86,15 @@ def test_winograd_kernels_fit_two_waves_per_simd(rows):
         args = r["demangled"].split("k_conv_wino<")[1].split(">")[0].split(",")
         cc, cw = int(args[2]), int(args[6])
         assert r["mfma"] == 8 * cc * cw, r      # two chunk bodies (first / other) x CC/4 steps x 16 CW MFMAs: straight-line
+
+
+def test_front_conv7_is_straight_line_and_fits_three_waves_per_simd(rows):
+    """k_conv7: NCG x 196 MFMAs of fully unrolled code per tile; the four-group instances (15 joints) within 168 registers."""
+    k7 = [r for r in rows if "k_conv7<" in r["demangled"]]
+    assert len(k7) == 4
+    for r in k7:
+        args = r["demangled"].split("k_conv7<")[1].split(">")[0].split(",")
+        ncg = int(args[1])
+        assert r["mfma"] == 196 * ncg, r
+        if ncg == 4:
+            assert r["vgpr"] + r["agpr"] <= 168, r
