@@ -1402,7 +1402,7 @@ extern "C" int fvp_pack_conv(const float* weight, const float* bias, const float
                        as_stream(s), weight, op->cin, op->cout, op->cinp, op->kh, op->kw, params + op->pair_off);
     if (op->kh == 7 && op->kw == 7) {                                  // k-grouped copy for k_conv7, behind the pixel-pair copy
       const int ncg = op->cin <= 16 ? 4 : ceil_div(op->cin, 4);        // (k_conv7 runs four groups for every cin <= 16)
-      hipLaunchKernelGGL(k_pack_k7, dim3(ceil_div(ncg * 49 * 64, 256)), dim3(256), 0, as_stream(s), weight, op->cin, op->cout, ncg,
+      hipLaunchKernelGGL(k_pack_k7, dim3(ceil_div(ncg * kK7GroupFloats, 256)), dim3(256), 0, as_stream(s), weight, op->cin, op->cout, ncg,
                          params + op->pair_off + size_t(op->cinp) * 7 * 8 * 32);
     }
   }

@@ -8,8 +8,9 @@
 //               output row j of the tile that the input row reaches (ky = r - j in 0..6), so an activation is read once per
 //               R output rows: (R + 6) * 7 reads per 49 R MFMAs.
 //   B operand = weights: lane (n = l & 15, g) holds Wt[n][4c + g][tap]: the 49 taps of a channel group live in 49
-//               registers, loaded with coalesced 256-byte global loads from the k-grouped copy [c][tap][g][n] that
-//               fvp_pack_conv writes behind the pixel-pair copy; the next group's 49 arrive under this group's MFMAs.
+//               registers (13 quads), loaded with 13 coalesced global_load_dwordx4 from the k-grouped copy
+//               [c][tap quad][g][n][4] that fvp_pack_conv writes behind the pixel-pair copy; the next group's arrive under
+//               this group's MFMAs.
 //   D         : lane holds pixels 4 g .. 4 g + 3 of cout n: one 16-byte store per output row.
 //
 // Against the pixel-pair form of k_conv_dma (32x32x2 tiles: rows 16..31 = the same couts one tap to the right, 8 tap
@@ -69,10 +70,12 @@ __global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? FVP_K7_OCC
   // epilogue vectors and the first channel group's weights: in flight under the tile DMA
   const int n = m;                                      // this lane's cout
   const float e_bias = a.epi[n], e_scale = a.epi[a.coutp + n], e_shift = a.epi[2 * a.coutp + n];
-  const float* wl = a.wts + lane;
-  float bw[2][49];
+  // 49 taps = 13 quads of 4 (the last one holds one tap): 13 global_load_dwordx4 per channel group instead of 49 dword
+  // loads - every vector instruction of a wave costs its SIMD ~12 cycles of matrix time
+  const float4* wl = reinterpret_cast<const float4*>(a.wts) + lane;
+  float4 bw[2][13];
 #pragma unroll
-  for (int tp = 0; tp < 49; ++tp) bw[0][tp] = wl[tp * 64];
+  for (int tq = 0; tq < 13; ++tq) bw[0][tq] = wl[tq * 64];
 
   // ---- input tile: [NCH][THp rows of (margin quad + W/4 quads)] + pad, one DMA round
   if (!(FVP_K7_ABLATE & 1)) {
@@ -83,16 +86,37 @@ __global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? FVP_K7_OCC
     rs[2] = a.cin * HW * 4;                             // channels >= cin fail the range check
     rs[3] = 0x00020000;
     const unsigned lds0 = FVP_LDS_BYTE_ADDRESS(smem);
+    // item j of this lane = item j - 1 + NT: (channel, row, quad) advance by compile-time steps with two carries instead of
+    // two divisions per item (the set-up in front of 784 MFMAs is matrix time too)
+    constexpr int kDCh = NT / QPC, kDRem = NT % QPC, kDRow = kDRem / QPR, kDQ = kDRem % QPR;
+    constexpr int kPadRow = QPC / QPR, kPadQ = QPC % QPR;       // a channel plane = kPadRow rows + kPadQ quads
+    const int it0 = wave * 64 + lane;
+    int ch = it0 / QPC, rem0 = it0 - ch * QPC;
+    int row = rem0 / QPR, q = rem0 - row * QPR;
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
-      const int it = (wave + NW * j) * 64 + lane;
-      if (it < NITEMS) {
-        const int ch = it / QPC, rem = it - ch * QPC;
-        const int row = rem / QPR, q = rem - row * QPR;
+      if ((wave + NW * j) * 64 + lane < NITEMS) {
         const int y = y0 - 3 + row;
         const bool ok = row < THp && q > 0 && y >= 0 && y < H;
         const unsigned vo = ok ? unsigned((ch * H + y) * W + 4 * (q - 1)) * 4u : 0x80000000u;
         asm_buffer_load_lds16(lds0 + unsigned(wave + NW * j) * 1024u, vo, rs, 0u);
+      }
+      ch += kDCh;
+      row += kDRow;
+      q += kDQ;
+      if (q >= QPR) {
+        q -= QPR;
+        ++row;
+      }
+      // past the end of the channel plane (row * QPR + q >= QPC): next channel
+      if (row > kPadRow || (row == kPadRow && q >= kPadQ)) {
+        ++ch;
+        row -= kPadRow;
+        q -= kPadQ;
+        if (q < 0) {
+          q += QPR;
+          --row;
+        }
       }
     }
   }
@@ -105,14 +129,22 @@ __global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? FVP_K7_OCC
 
   const float* xs = smem + g * CS + wave * 16 + m + 1;  // channel g of a group, pixel x0 + m, tap kx = 0 (margin 4 - pad 3)
   float av[2][7];
+  // One opaque word offset per three rows: the reads of those rows are `base + small constant` (ds_read2_b32 reaches 255
+  // words); left to itself hipcc rebuilds a base for almost every read pair (191 v_add_u32 per tile, 0.24 per MFMA).
+  int boff = 0;
   auto fetch = [&](int set, int c, int r) {
+    if (r % 3 == 0) {
+      boff = c * 4 * CS + r * WP;
+      FVP_OPAQUE_V(boff);
+    }
+    const float* rowp = xs + boff + (r % 3) * WP;
 #pragma unroll
     for (int kx = 0; kx < 7; ++kx) {
       if (FVP_K7_ABLATE & 2) {
         av[set][kx] = float(lane + kx);
         FVP_OPAQUE_V(av[set][kx]);
       } else {
-        av[set][kx] = xs[c * 4 * CS + r * WP + kx];
+        av[set][kx] = rowp[kx];
       }
     }
   };
@@ -121,7 +153,7 @@ __global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? FVP_K7_OCC
   for (int c = 0; c < NCG; ++c) {
     if (c + 1 < NCG && !(FVP_K7_ABLATE & 4)) {
 #pragma unroll
-      for (int tp = 0; tp < 49; ++tp) bw[(c + 1) & 1][tp] = wl[((c + 1) * 49 + tp) * 64];
+      for (int tq = 0; tq < 13; ++tq) bw[(c + 1) & 1][tq] = wl[((c + 1) * 13 + tq) * 64];
     }
 #pragma unroll
     for (int r = 0; r < THp; ++r) {
@@ -136,8 +168,12 @@ __global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? FVP_K7_OCC
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           const int ky = r - j;
-          if (ky >= 0 && ky < 7)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][kx], bw[(FVP_K7_ABLATE & 4) ? 0 : (c & 1)][ky * 7 + kx], acc[j], 0, 0, 0);
+          if (ky >= 0 && ky < 7) {
+            const int tp = ky * 7 + kx;
+            const float4& wq = bw[(FVP_K7_ABLATE & 4) ? 0 : (c & 1)][tp >> 2];
+            const float wv = (tp & 3) == 0 ? wq.x : (tp & 3) == 1 ? wq.y : (tp & 3) == 2 ? wq.z : wq.w;
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][kx], wv, acc[j], 0, 0, 0);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -162,15 +198,16 @@ __global__ void __launch_bounds__(W / 16 * 64, (NCG == 4 && R <= 4) ? FVP_K7_OCC
   }
 }
 
-// k-grouped copy of a 7x7 conv's weights [cout][cin][7][7] for k_conv7: [c][tap][g][n] = w[n][4 c + g][tap], zero for
-// channels >= cin and couts >= cout.
+// k-grouped copy of a 7x7 conv's weights [cout][cin][7][7] for k_conv7: [c][tap quad tq][lane = g * 16 + n][e] =
+// w[n][4 c + g][tap 4 tq + e], zero for channels >= cin, couts >= cout and taps >= 49 (13 quads per channel group).
+constexpr int kK7GroupFloats = 13 * 64 * 4;
 __global__ void __launch_bounds__(256) k_pack_k7(const float* __restrict__ w, int cin, int cout, int ncg, float* __restrict__ dst) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= ncg * 49 * 64) return;
-  const int n = i & 15, g = (i >> 4) & 3, r = i >> 6;
-  const int tp = r % 49, c = r / 49;
-  const int ch = 4 * c + g;
-  dst[i] = (ch < cin && n < cout) ? w[(size_t(n) * cin + ch) * 49 + tp] : 0.0f;
+  if (i >= ncg * kK7GroupFloats) return;
+  const int e = i & 3, n = (i >> 2) & 15, g = (i >> 6) & 3, r = i >> 8;
+  const int tq = r % 13, c = r / 13;
+  const int ch = 4 * c + g, tp = 4 * tq + e;
+  dst[i] = (ch < cin && n < cout && tp < 49) ? w[(size_t(n) * cin + ch) * 49 + tp] : 0.0f;
 }
 
 }  // namespace fvp

@@ -214,7 +214,7 @@ class StackSpec:
                     pair_off = off                      # pixel-pair layout [cinp][7][8][32] ...
                     off += cinp * 7 * 8 * 32
                     ncg = 4 if o["cin"] <= 16 else -(-o["cin"] // 4)
-                    off += ncg * 49 * 64                # ... + the k-grouped copy [max(4, ceil(cin/4))][49][4][16] (k_conv7)
+                    off += ncg * 13 * 64 * 4            # ... + the k-grouped copy [max(4, ceil(cin/4))][13 tap quads][4][16][4] (k_conv7)
                 if (o["kind"] == capi.OP_CONVT2 and o["h"] > 1 and o["w"] % 4 == 0 and coutp in (32, 64)):
                     pair_off = off                      # column-tap pairs [dy][cinp][dx*coutp + co]
                     off += 4 * cinp * coutp

@@ -172,7 +172,7 @@ typedef struct FvpConvOp {
                               /* as F(2x2,3x3) (requires even H, W a power of two)           */
   int32_t pair_off;           /* 0, or float offset of the pixel-pair copy of the weights:    */
                               /* 7x7 conv with cout <= 16 -> [cinp][7][8][32], followed by the */
-                              /* k-grouped copy [max(4, ceil(cin/4))][49][4][16] (ABI 7,       */
+                              /* k-grouped copy [max(4,ceil(cin/4))][13][4][16][4] (ABI 7,     */
                               /* fvp_conv7.h); 2-D ConvTranspose(k2,s2) ->                     */
                               /* [dy][cinp][dx*coutp+co] (fvp_conv.hip)                        */
 } FvpConvOp;
