@@ -360,3 +360,44 @@ def test_joint_and_view_count_extremes(emu_lib, J, V):
     with torch.no_grad():
         model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
     assert torch.equal(model.engine.last_jln["planes"], planes_fused)
+
+
+@pytest.mark.parametrize("net,args", [("centernet", (15, 80, 80)), ("centernet", (17, 80, 80)), ("p2pnet", (15, 15, 64)),
+                                      ("p2pnet", (17, 17, 64)), ("p2pnet", (15, 15, 128)), ("c2cnet", (15, 20))])
+def test_packed_parameter_blob_layout(emu_lib, net, args):
+    """netspec.finalize() (host) and fvp_pack_conv (library) must agree on the parameter blob: every op's copies - packed
+    weights, epilogue vectors, the Winograd-domain copy, the pixel-pair + k-grouped copies of the 7x7 front conv, the
+    column-tap pairs of the transposed convs - at the BASELINE shapes.  Each op is packed into a blob of sentinels: what it
+    writes lies inside [64, nparams), is disjoint from every other op's writes, and the first 64 floats (the zero page)
+    and the guard behind the blob stay untouched."""
+    import ctypes as C
+
+    from faster_voxelpose_amd import _capi as capi
+    from faster_voxelpose_amd import netspec
+    spec = {"centernet": netspec.centernet_spec, "p2pnet": netspec.p2pnet_spec, "c2cnet": netspec.c2cnet_spec}[net](*args)
+    guard = 8192
+    sentinel = 12345.678
+    blob = torch.full((spec.nparams + guard,), sentinel)
+    g = torch.Generator().manual_seed(3)
+    owner = torch.full((spec.nparams + guard,), -1, dtype=torch.int32)
+    for key, bn, transposed, oi in spec.param_keys:
+        shape = spec.entries[key + ".weight"][0]
+        w = (torch.rand(shape, generator=g) + 0.5).contiguous()       # never equal to the sentinel, never zero
+        b = torch.rand(shape[1] if transposed else shape[0], generator=g) + 0.5
+        bnp = [None] * 4
+        if bn is not None:
+            c = spec.entries[bn + ".weight"][0]
+            bnp = [torch.rand(c, generator=g) + 0.5 for _ in range(4)]
+        before = blob.clone()
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        capi.check(emu_lib, emu_lib.fvp_pack_conv(ptr(w), ptr(b), *[ptr(t) for t in bnp], 1e-5, 1 if transposed else 0,
+                                                  C.byref(spec.op_array[oi]), ptr(blob), None), "fvp_pack_conv")
+        touched = (blob != before).nonzero().flatten()
+        assert touched.numel() > 0, key
+        assert int(touched.min()) >= 64 and int(touched.max()) < spec.nparams, (key, int(touched.min()), int(touched.max()))
+        assert bool((owner[touched] == -1).all()), "%s writes into the region of op %d" % (key, int(owner[touched].max()))
+        owner[touched] = oi
+    assert bool((blob[:64] == sentinel).all()) and bool((blob[spec.nparams:] == sentinel).all())
+    # ... and nothing inside is left unwritten (a kernel would read it) beyond the round-up-to-4 gaps between regions
+    unwritten = int((owner[64:spec.nparams] == -1).sum())
+    assert unwritten <= 3 * 2 * len(spec.param_keys), unwritten
