@@ -401,3 +401,22 @@ def test_packed_parameter_blob_layout(emu_lib, net, args):
     # ... and nothing inside is left unwritten (a kernel would read it) beyond the round-up-to-4 gaps between regions
     unwritten = int((owner[64:spec.nparams] == -1).sum())
     assert unwritten <= 3 * 2 * len(spec.param_keys), unwritten
+
+
+def test_front_conv7_random_shapes(emu_lib):
+    """k_conv7 over random (joints, height, planes, mask) draws: heights 4..19 (every remainder of the 4-row tile), 1..20
+    channels (1..5 channel groups, ragged last group), masked planes.  Against a float64 torch evaluation."""
+    rng = np.random.default_rng(11)
+    for _ in range(8):
+        cin = int(rng.integers(1, 21))
+        h = int(rng.integers(4, 20))
+        w_ = int(rng.choice([64, 128]))
+        planes = int(rng.integers(1, 4))
+        spec, w, ref, o = front7_stack(cin, (h, w_), seed=cin + h)
+        x = torch.from_numpy(rng.normal(size=(planes, cin, h, w_)).astype(np.float32))
+        valid = torch.from_numpy((rng.random(planes) < 0.7).astype(np.uint8))
+        valid[0] = 1
+        got = run_custom_conv_stack(emu_lib, "cpu", spec, w, x, plane_valid=valid)[o]
+        keep = valid.bool()
+        np.testing.assert_allclose(got[keep].double().numpy(), ref(x[keep]).numpy(), rtol=2e-5, atol=2e-5,
+                                   err_msg=str((cin, h, w_, planes)))
