@@ -1184,7 +1184,8 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   // 64 / 128 columns (P2PNet: 30 planes per frame); CenterNet's 80 x 80 map (one plane per frame) stays on the pixel-pair
   // form - 8 planes: 25.9 us there, 28.9-29.9 us here (160 one-tile workgroups of 784 chained MFMAs per wave).
   if (!tr && kh == 7 && kw == 7 && op.pair_off > 0 && !kNoK7 && op.cout <= 16 && !(op.flags & FVP_EPI_RES) && !pool_dst && !head &&
-      (op.w == 64 || op.w == 128) && op.cin <= 20 && op.h >= 4) {
+      (op.w == 64 || op.w == 128) && op.cin <= 20 && op.h >= 4 &&
+      double(op.cin + 4) * op.h * op.w * 4.0 < 2147483648.0) {       // 32-bit byte offsets inside a plane group (buffer addressing)
     const int ncg = op.cin <= 16 ? 4 : 5;
     a.wts = params + op.pair_off + size_t(op.cinp) * 7 * 8 * 32;       // the k-grouped copy behind the pixel-pair copy
     a.tiles_y = ceil_div(op.h, kK7Rows);
