@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfvp_hip.so"
-ABI_VERSION = 7            # include/fvp.h FVP_ABI_VERSION
+ABI_VERSION = 8            # include/fvp.h FVP_ABI_VERSION
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 FVP_CAM_FLOATS = 24
@@ -67,7 +67,7 @@ SIGNATURES = {
     "fvp_pack_conv": [_P, _P, _P, _P, _P, _P, _F, _I, C.POINTER(FvpConvOp), _P, _P],
     "fvp_nms_topk": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
     "fvp_gather_proposals": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
-    "fvp_proposals": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P],
+    "fvp_proposals": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P],
     "fvp_proposal_layer": [_P, _P, _P, _P, _F, _I, _I, _P, _P],
     "fvp_softargmax_weightnet": [_P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "fvp_pack_weightnet": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P, _P],

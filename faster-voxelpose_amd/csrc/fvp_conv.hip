@@ -1179,13 +1179,14 @@ static int plan_and_launch(const FvpConvOp& op, const float* params, float* cons
   const int CBfull = op.coutp / 32;
   if (CBfull != 1 && CBfull != 2 && CBfull != 4) return FVP_ELIMIT;
   a.ablate = kAblate;
-  if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp && op.cout % 32 == 0) return wino_plan_and_launch(op, a, params, planes, s);
+  if (!tr && op.wino_off > 0 && !kNoWino && op.cin == op.cinp && op.cout % 32 == 0 && op.cout == op.coutp) return wino_plan_and_launch(op, a, params, planes, s);
   // 7x7 front conv on 16x16x4 tiles (k_conv7): a SHAPE rule (map width, channels), never the number of planes.  Maps of
   // 64 / 128 columns (P2PNet: 30 planes per frame); CenterNet's 80 x 80 map (one plane per frame) stays on the pixel-pair
   // form - 8 planes: 25.9 us there, 28.9-29.9 us here (160 one-tile workgroups of 784 chained MFMAs per wave).
   if (!tr && kh == 7 && kw == 7 && op.pair_off > 0 && !kNoK7 && op.cout <= 16 && !(op.flags & FVP_EPI_RES) && !pool_dst && !head &&
       (op.w == 64 || op.w == 128) && op.cin <= 20 && op.h >= 4 &&
-      double(op.cin + 4) * op.h * op.w * 4.0 < 2147483648.0) {       // 32-bit byte offsets inside a plane group (buffer addressing)
+      double(4 * (op.cin <= 16 ? 4 : 5)) * op.h * op.w * 4.0 < 2147483648.0) {   // 32-bit byte offsets of all 4 * NCG channel slots (channels >= cin
+                                                                                 // must stay out of range, never wrap: ADVICE round 5)
     const int ncg = op.cin <= 16 ? 4 : 5;
     a.wts = params + op.pair_off + size_t(op.cinp) * 7 * 8 * 32;       // the k-grouped copy behind the pixel-pair copy
     a.tiles_y = ceil_div(op.h, kK7Rows);
@@ -1351,7 +1352,7 @@ extern "C" int fvp_conv_stack_run(const FvpConvOp* ops, int nops, const float* p
       rc = launch_status();
     } else if (op.kind == FVP_OP_CONV || op.kind == FVP_OP_CONVT2) {
       float* pool_dst = nullptr;
-      if (op.kind == FVP_OP_CONV && op.wino_off > 0 && op.cin == op.cinp && op.cout % 32 == 0 && !kNoWino && !kNoPoolFuse) {
+      if (op.kind == FVP_OP_CONV && op.wino_off > 0 && op.cin == op.cinp && op.cout % 32 == 0 && op.cout == op.coutp && !kNoWino && !kNoPoolFuse) {
         for (int j = i + 1; j < nops && j < 64; ++j)
           if (ops[j].kind == FVP_OP_POOL2 && ops[j].src == op.dst && ops[j].h == op.h && ops[j].w == op.w &&
               ops[j].h > 1 && ops[j].cin == op.cout && ops[j].dst >= 0 && ops[j].dst < nbufs) {

@@ -733,7 +733,9 @@ static int launch_wino(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, 
 
 int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, int planes, hipStream_t s) {
   int WC, WT, TN, TR;
-  if (op.cout % 32 != 0) return FVP_EINVAL;         // whole 32-cout blocks only: the epilogue has no per-cout predicate
+  // whole 32-cout blocks only, and no padded couts: the epilogue has no per-cout predicate and its descriptor spans the
+  // plane group, so a block of padding couts (cout = 96, coutp = 128) would be written into the next plane
+  if (op.cout % 32 != 0 || op.cout != op.coutp) return FVP_EINVAL;
   if (!wino_tiling(op.h, op.w, op.cinp, op.coutp, &WC, &WT, &TN, &TR, kWinoHalf == 1)) return FVP_EINVAL;
   if (kWinoHalf == 0) {
     // full-size units: (rows bands) x (plane groups) x (cout blocks); switch to half-size ones when they cannot fill the CUs

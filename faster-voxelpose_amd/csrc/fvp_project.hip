@@ -438,6 +438,7 @@ k_project_columns_q(const float* __restrict__ heat_cl, const Cam* __restrict__ c
     }
 }
 
+#if FVP_DIAG   // the round-1 gather form of the fused projection: diagnostics build only (FVP_TRIPLANE_GATHER=1)
 template <int NVL>   // channel quads per lane: ceil(JP/16)
 __global__ void __launch_bounds__(1024)
 k_project_triplane(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
@@ -575,6 +576,8 @@ k_project_triplane(const float* __restrict__ heat_cl, const Cam* __restrict__ ca
       }
   }
 }
+
+#endif  // FVP_DIAG
 
 }  // namespace fvp
 #include "fvp_project_lds.h"
@@ -802,11 +805,18 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   // persons_per_frame > 0 promises person p belongs to frame p / persons_per_frame (used only to
   // place the workgroups of one frame on one XCD); 0 = unknown
   const int ppf = (persons_per_frame > 0 && nP % persons_per_frame == 0) ? persons_per_frame : nP;
-  const int chunks = ceil_div(C * C, 256);
+  [[maybe_unused]] const int chunks = ceil_div(C * C, 256);      // (the diagnostics build's gather form)
   const int nvl = ceil_div(g->JP, 16);
   ProfScope ps(FVP_K_PROJECT_TRIPLANE, as_stream(s));
-  // default: heatmap footprint staged in LDS (fvp_project_lds.h); FVP_TRIPLANE_GATHER=1 selects the first fused
-  // kernel (every tap through the texture path) for comparison
+  // The shipped form for every joint count (JP <= 32) is the UNSTAGED compact-block kernel k_project_triplane_blk (round 4:
+  // Panoptic 494 -> 348 us, Shelf 709 -> 592 us, Campus 161 -> 158 us against the LDS-staged forms, same bits; lanes whose
+  // channel quad lies beyond JP idle, so miniature joint counts run it too).  The LDS-staged quad / lane-per-voxel forms
+  // and the round-1 gather form exist in the diagnostics build only (round 6), behind FVP_TRIPLANE_STAGED / _LANE /
+  // _QUAD / _GATHER; they give the same bits (tests/test_emu_kernels.py, tools/gpu_switch_matrix.sh).
+  const int F0 = fine_grid ? fine[0] : 0, F1 = fine_grid ? fine[1] : 0, F2 = fine_grid ? fine[2] : 0;
+  const int nby = ceil_div(C, kBY);
+#if FVP_DIAG
+  const int nbx = ceil_div(C, kBX);
   static const bool gather = fvp::diag_env("FVP_TRIPLANE_GATHER") != nullptr;
   // FVP_TRIPLANE_QUAD=1: the round-2 form of the LDS-staged kernel (four lanes per voxel) instead of one lane per voxel
   const bool quad_form = fvp::diag_env("FVP_TRIPLANE_QUAD") != nullptr;            // read per call: tests switch it
@@ -818,27 +828,18 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
   // the quad form's gather runs on the otherwise idle texture path beside the LDS reads of the staged rectangles).
   // FVP_TRI_TWO_TILE=0/1 overrides.
   const char* tt_env = fvp::diag_env("FVP_TRI_TWO_TILE");
-  // Default for JP >= 16 (every shipped shape): the UNSTAGED compact-block form k_project_triplane_blk (round 4) - Panoptic
-  // 494 -> 348 us, Shelf 709 -> 592 us, Campus 161 -> 158 us against the LDS-staged forms, same bits.  The staged forms stay
-  // selectable in the diagnostics build (FVP_TRIPLANE_STAGED=1: quad form for JP = 16, lane-per-voxel form for JP = 20) and
-  // the lane-per-voxel form remains the default for JP <= 12 (miniature shapes: the quad lanes would idle).
   const bool staged = fvp::diag_env("FVP_TRIPLANE_STAGED") != nullptr;
-  const bool lane_form = !gather && !quad_form && g->JP <= 20 && g->JP != 16 && (staged || g->JP < 16);
+  const bool force_lane = fvp::diag_env("FVP_TRIPLANE_LANE") != nullptr;           // read per call: tests switch it
+  // lane-per-voxel staged form: JP = 4 .. 12 and 20 (JP = 16 stages through the quad form; JP 24 .. 32 would spill)
+  const bool lane_form = !gather && !quad_form && g->JP <= 20 && ((staged && g->JP != 16) || force_lane);
   const int tri_ablate = (tri_ablate_env & ~16) | ((tt_env ? atoi(tt_env) != 0 : lane_form) ? 16 : 0);
   // tests: FVP_TRI_CAP_PX lowers the rectangle size the kernel treats as fitting a tile (the allocation is unchanged),
   // so that one-tile, two-tile and global-gather rectangles all occur on small fixtures; read per call
   auto cap_lim = [](int cap) { const char* e = fvp::diag_env("FVP_TRI_CAP_PX"); const int v = e ? atoi(e) : cap; return v > 0 && v < cap ? v : cap; };
-  const int F0 = fine_grid ? fine[0] : 0, F1 = fine_grid ? fine[1] : 0, F2 = fine_grid ? fine[2] : 0;
-  const int nbx = ceil_div(C, kBX), nby = ceil_div(C, kBY);
   // two tiles per workgroup, two workgroups (512 threads, <= 128 VGPRs) per CU: 4 x 36 KB + state
   const int cap_px = int((36 * 1024) / (size_t(g->JP) * 4));
   const size_t lds = 2 * size_t(cap_px) * g->JP * 4 + 64;
-  // lane-per-voxel form for JP = 4 .. 12 and 20 (J = 17: Shelf / Campus, where the quad form needs two channel quads per
-  // lane and 16-deep blocks): Campus 222 -> 160 us, Shelf 756 -> 714 us for 80 / 40 people.  JP = 16 (Panoptic) stays
-  // on the quad form (490 vs 616 us: more than half of its rectangles exceed a tile and are gathered, which the quad
-  // form does with 4x fewer cache lines per instruction); JP 24 .. 32 would spill.  FVP_TRIPLANE_LANE=1 forces it.
-  static const bool force_lane = fvp::diag_env("FVP_TRIPLANE_LANE") != nullptr;
-  if (lane_form || (force_lane && !gather && g->JP <= 20)) {
+  if (lane_form) {
     const int lq = (g->JP / 4) | 1;                                           // tile pixel pitch in quads (odd)
     const int cap_px = int((36 * 1024) / (size_t(lq) * 16));
     const size_t lds = 2 * size_t(cap_px) * lq * 16 + 64;
@@ -861,9 +862,13 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
 #undef CALL2
     return launch_status();
   }
+  const bool blk_form = !gather && !quad_form && !staged;
+#else
+  constexpr bool blk_form = true;
+#endif
   // JP = 16 (Panoptic): the compact-block form WITHOUT LDS staging (k_project_triplane_blk, round 4).  FVP_TRIPLANE_STAGED=1
   // (diagnostics build) keeps the staged quad form for comparison; both give the same bits.
-  if (!gather && nvl <= 2 && !quad_form && !staged && (nvl == 2 || g->JP == 16)) {
+  if (blk_form && nvl <= 2) {
     const int nbx2 = ceil_div(C, kBlkBX);
     const int bz = nvl == 2 ? 16 : kBlkBZ;
     // z-resident cells (ZRES, diagnostics build only: FVP_TRI_ZRES=1).  Measured in round 5, same box, same bits: Panoptic
@@ -901,6 +906,7 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
 #undef CALLB
     return launch_status();
   }
+#if FVP_DIAG
   if (!gather && nvl <= 2) {
     FVP_LIMIT(cap_px >= kBX * kBY + (kBX + kBY) * (nvl == 1 ? 32 : 16));      // the block's plane cells alias tile 0
 #define CALL(NVL_, CACHED_)                                                                                        \
@@ -932,4 +938,7 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
     return FVP_ELIMIT;
   }
   return launch_status();
+#else
+  return FVP_ELIMIT;                                     // more than 32 joint channels
+#endif
 }

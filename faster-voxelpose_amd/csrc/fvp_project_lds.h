@@ -99,6 +99,7 @@ constexpr int kBX = 8, kBY = 4;                 // voxel block of a workgroup in
                                                // lane) or 16 (two: J = 17), so that both forms stay within 128 VGPRs
 constexpr int kTriThreads = kBX * kBY * 4 * 4; // (x, y, zs) slots x 4 channel-quad lanes = 512
 
+#if FVP_DIAG   // the LDS-staged forms are diagnostics-build code (round 6): no shipped shape launches them
 // CACHED: sampling coordinates come from the per-sequence cache `fgrid` ([nsets][V][F0*F1*F2][2], the reference's
 // cached grid) instead of being recomputed: 2 coalesced 8-byte loads per lane and view replace ~230 VALU
 // instructions (the projection was ~45 % of the kernel's VALU work).
@@ -448,6 +449,8 @@ k_project_triplane_lds(const float* __restrict__ heat_cl, const Cam* __restrict_
   }
 }
 
+#endif  // FVP_DIAG
+
 // ---------------------------------------------------------------------------------------------------------------
 // Round 4: the quad form WITHOUT LDS staging.  Measured in round 3: with every rectangle forced onto the global-gather
 // path the staged quad kernel takes 493 us against 490 - its sampling is bound by the instruction stream, and the compact
@@ -757,6 +760,7 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
   }
 }
 
+#if FVP_DIAG
 // ---------------------------------------------------------------------------------------------------------------
 // Round 3: the same kernel with ONE LANE PER VOXEL (all JP channels) instead of four lanes per voxel (a channel quad
 // each).  Ablations of the quad form (80 people, FVP_TRI_ABLATE): 494 us complete = 225 us sampling + 104 us
@@ -1048,5 +1052,7 @@ k_project_triplane_lds2(const float* __restrict__ heat_cl, const Cam* __restrict
     __syncthreads();
   }
 }
+
+#endif  // FVP_DIAG
 
 }  // namespace fvp

@@ -132,7 +132,7 @@ k_gather(const float* __restrict__ bbox_map, const float* __restrict__ cubes, co
 __global__ void __launch_bounds__(64)
 k_proposals(const float* __restrict__ hm1d, const float* __restrict__ conf2d, const long long* __restrict__ idx2d,
             const float* __restrict__ match_bbox, const float* __restrict__ sb, float min_score, int BN, int Z,
-            long long* __restrict__ topk_index, float* __restrict__ centers) {
+            long long* __restrict__ topk_index, float* __restrict__ centers, unsigned char* __restrict__ valid) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= BN) return;
   const float* h = hm1d + size_t(i) * Z;
@@ -156,6 +156,7 @@ k_proposals(const float* __restrict__ hm1d, const float* __restrict__ conf2d, co
   c[4] = conf;
   c[5] = match_bbox[size_t(i) * 2];
   c[6] = match_bbox[size_t(i) * 2 + 1];
+  if (valid) valid[i] = c[3] >= 0.0f;            // faster_voxelpose.py:45 (mask = proposal_centers[:, :, 3] >= 0)
 }
 
 // ProposalLayer.forward on its own (human_detection_net.py:44-65, eval branch): same arithmetic as the tail of k_proposals
@@ -212,13 +213,13 @@ extern "C" int fvp_gather_proposals(const float* bbox_map, const float* cubes, c
 
 extern "C" int fvp_proposals(const float* hm1d, const float* conf2d, const int64_t* idx2d, const float* match_bbox,
                              const float* sb, float min_score, int B, int N, int Z, int64_t* topk_index,
-                             float* centers, fvp_stream_t s) {
+                             float* centers, uint8_t* valid, fvp_stream_t s) {
   FVP_REQUIRE(hm1d && conf2d && idx2d && match_bbox && sb && centers && B >= 0 && N > 0 && Z > 0);
   if (B == 0) return 0;
   ProfScope ps(FVP_K_OTHER, as_stream(s));
   hipLaunchKernelGGL(k_proposals, dim3(ceil_div(B * N, 64)), dim3(64), 0, as_stream(s), hm1d, conf2d,
                      reinterpret_cast<const long long*>(idx2d), match_bbox, sb, min_score, B * N, Z,
-                     reinterpret_cast<long long*>(topk_index), centers);
+                     reinterpret_cast<long long*>(topk_index), centers, valid);
   return launch_status();
 }
 

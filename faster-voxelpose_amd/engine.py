@@ -335,21 +335,25 @@ class HotPath:
                    self.F, self.Hd, _ptr(self.wn_params), self.stream())
 
     # ---- conv stack ----------------------------------------------------------------------------------------
-    def run_stack(self, name, x, planes, plane_valid=None, valid_div=1):
+    def run_stack(self, name, x, planes, plane_valid=None, valid_div=1, fresh=()):
+        """`fresh`: output names whose buffer is a new tensor instead of the stack's reused scratch - the caller may hand it
+        out (HDN's public heatmaps) without a copy launch."""
         spec = self.specs[name]
         bufs = [x]
+        own = {spec.outputs[k] for k in fresh}
         for i, (c, h, w) in enumerate(spec.bufs[1:], start=1):
-            bufs.append(self.scratch(f"{name}.buf{i}", (planes, c, h, w)))
+            bufs.append(torch.empty((planes, c, h, w), device=self.device) if i in own
+                        else self.scratch(f"{name}.buf{i}", (planes, c, h, w)))
         arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
         self._call("fvp_conv_stack_run", spec.op_array, len(spec.ops), _ptr(self.params[name]), arr, len(bufs),
                    planes, _ptr(plane_valid), valid_div, self.stream())
         return {k: bufs[i] for k, i in spec.outputs.items()}
 
-    def run_stack_fused_1d(self, name, x, planes):
+    def run_stack_fused_1d(self, name, x, planes, fresh=False):
         """Whole 1-D stack in one kernel (fvp_conv_stack_run_fused_1d); x = [planes, cin, 1, W]."""
         spec = self.specs[name]
         c, h, w = spec.bufs[spec.outputs["out"]]
-        out = self.scratch(f"{name}.fused_out", (planes, c, h, w))
+        out = torch.empty((planes, c, h, w), device=self.device) if fresh else self.scratch(f"{name}.fused_out", (planes, c, h, w))
         self._call("fvp_conv_stack_run_fused_1d", spec.op_array, len(spec.ops), _ptr(self.params[name]), _ptr(x),
                    _ptr(out), planes, self.stream())
         return {"out": out}
@@ -384,8 +388,8 @@ class HotPath:
         s = self.stream()
         keep = self.keep_hdn_cubes
         cubes, zmax = self.project_whole(heatmaps, meta, cameras, resize_transform, keep, True)
-        heads = self.run_stack("center_net", zmax, B)
-        hm2d = heads["output_hm"].clone()
+        heads = self.run_stack("center_net", zmax, B, fresh=("output_hm",))     # returned to the caller: its own tensor
+        hm2d = heads["output_hm"]
         bbox_map = heads["output_size"]
         dev = self.device
         conf2d = self.scratch("conf2d", (B, N))
@@ -407,15 +411,17 @@ class HotPath:
                        _ptr(self.frame_sets(meta, cameras, heatmaps.shape[1])), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
                        X, Y, Z, B, C.byref(g), _ptr(flat), N, _ptr(feat1d), s)
         if self.fused_c2c and Z <= 24:
-            hm1d = self.run_stack_fused_1d("c2c_net", feat1d, B * N)["out"].view(B, N, Z).clone()
+            hm1d = self.run_stack_fused_1d("c2c_net", feat1d, B * N, fresh=True)["out"].view(B, N, Z)
         else:
-            hm1d = self.run_stack("c2c_net", feat1d, B * N)["out"].view(B, N, Z).clone()
+            hm1d = self.run_stack("c2c_net", feat1d, B * N, fresh=("out",))["out"].view(B, N, Z)
         centers = torch.empty((B, N, 7), device=dev)
         topk_index = self.scratch("topk_index", (B, N, 3), torch.int64)
+        # `mask = proposal_centers[:, :, 3] >= 0` (faster_voxelpose.py:45) comes out of the same launch (ABI 8)
+        valid = self.scratch("proposal_valid", (B, N), torch.uint8)
         self._call("fvp_proposals", _ptr(hm1d), _ptr(conf2d), _ptr(idx2d), _ptr(match_bbox), _ptr(self.prop_sb),
-                   self.min_score, B, N, Z, _ptr(topk_index), _ptr(centers), s)
+                   self.min_score, B, N, Z, _ptr(topk_index), _ptr(centers), _ptr(valid), s)
         self.last = dict(cubes=cubes, zmax=zmax, conf2d=conf2d, idx2d=idx2d, flat=flat, topk_index=topk_index,
-                         bbox_map=bbox_map, feat1d=feat1d, hm2d=hm2d, hm1d=hm1d, bbox_flat=bbox_flat)
+                         bbox_map=bbox_map, feat1d=feat1d, hm2d=hm2d, hm1d=hm1d, bbox_flat=bbox_flat, valid=valid)
         return hm2d, hm1d, centers, bbox_flat
 
     def proposal_layer(self, topk_index, topk_confs, match_bbox, min_score):
@@ -488,7 +494,8 @@ class HotPath:
         g.V = V
         fs = self.frame_sets(meta, cameras, V)
         hcl = self.heat_cl(heatmaps, g, reuse=reuse_staging)
-        valid = mask.reshape(-1).to(torch.uint8).contiguous()
+        # (the forward hands over the uint8 flags fvp_proposals wrote: no launch; a caller's bool mask is converted)
+        valid = mask.reshape(-1) if (mask.dtype == torch.uint8 and mask.is_contiguous()) else mask.reshape(-1).to(torch.uint8).contiguous()
         pf = self.person_frame(B, N)
         centers2d = proposal_centers.view(nP, 7)
         boxes, offset = self.person_boxes(centers2d)

@@ -48,7 +48,7 @@ class FasterVoxelPoseNet(nn.Module):
                 num_views = views.shape[1]
                 input_heatmaps = torch.stack([backbone(views[:, c]) for c in range(num_views)], dim=1)
         _, _, proposal_centers, _ = self.pose_net(input_heatmaps, meta, cameras, resize_transform)
-        mask = proposal_centers[:, :, 3] >= 0
+        mask = self.engine.last["valid"]              # uint8 [B,N] = proposal_centers[:, :, 3] >= 0 (:45), written by fvp_proposals
         fused_poses, plane_poses = self.joint_net.forward5(meta, input_heatmaps, proposal_centers, mask, cameras,
                                                            resize_transform, _reuse_staging=True)
         # the channels-last staging copy is valid for this call only: a later tensor may reuse the
@@ -75,9 +75,13 @@ class GraphedForward:
             for _ in range(warmup):                      # packs weights, fills caches, sizes scratch
                 model(input_heatmaps=self.static_in, **self.args)
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().synchronize()
+        geo = model.engine.geo
+        geo.pending = [ev for ev in geo.pending if not ev.query()]     # nothing left to query inside the capture
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = model(input_heatmaps=self.static_in, **self.args)
+        self._pinned = (geo.cams, geo.fine_grid)        # the graph reads these through raw pointers: keep them alive
 
     def __call__(self, input_heatmaps=None):
         if input_heatmaps is not None and input_heatmaps.data_ptr() != self.static_in.data_ptr():
@@ -160,7 +164,7 @@ class GraphedPipeline:
         self.pipe = PipelinedForward(model, depth=depth, streams=streams)
         self.depth, self._i = depth, 0
         args = dict(meta=meta, cameras=cameras, resize_transform=resize_transform)
-        self.static_in, self.graphs, self.outs = [], [], []
+        self.static_in, self.graphs, self.outs, self._pinned = [], [], [], []
         cur = torch.cuda.current_stream()
         for k in range(depth):
             st, m = self.pipe.streams[k], self.pipe.models[k]
@@ -169,10 +173,18 @@ class GraphedPipeline:
             with torch.cuda.stream(st), torch.no_grad():
                 for _ in range(warmup):                  # packs weights, fills the shared caches, sizes the scratch
                     m(input_heatmaps=buf, **args)
-            st.synchronize()                             # (pending geometry rebuilds have completed: nothing to wait for in the capture)
+            st.synchronize()                             # pending geometry rebuilds have completed ...
+            # ... so their events are dropped BEFORE the capture: Event.query() inside a capture is legal on HIP today but
+            # not under CUDA's global capture mode - _await_geometry then has nothing to query
+            geo = m.engine.geo
+            geo.pending = [ev for ev in geo.pending if not ev.query()]
+            assert not geo.pending, "a geometry rebuild is still running on another stream: synchronise before capturing"
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st), torch.no_grad():
                 out = m(input_heatmaps=buf, **args)
+            # the graph holds RAW pointers to the shared camera table / coordinate cache: keep those tensors alive for the
+            # graph's lifetime, whatever an eager run with a new sequence retires later
+            self._pinned.append((geo.cams, geo.fine_grid))
             self.static_in.append(buf)
             self.graphs.append(g)
             self.outs.append(out)

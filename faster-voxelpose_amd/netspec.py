@@ -71,7 +71,7 @@ def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None, cout=None):
         return False
     if cin is not None and cin != cinp:          # whole channel chunks only (no padded input channels)
         return False
-    if cout is not None and cout % 32:           # whole 32-cout blocks only (round 5: the epilogue has no per-cout predicate)
+    if cout is not None and (cout % 32 or cout != coutp):   # whole 32-cout blocks, no padded couts (the epilogue has no per-cout predicate)
         return False
     if w & (w - 1) and not WINO_GENERIC:
         return False                             # rows that do not divide the workgroup tile: direct kernel by default

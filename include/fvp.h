@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FVP_ABI_VERSION 7
+#define FVP_ABI_VERSION 8
 #define FVP_MAX_VIEWS 8
 #define FVP_CAM_FLOATS 24 /* R[9] T[3] fx fy cx cy k[3] p[2] + 3 pad */
 #define FVP_MAX_JOINTS 32
@@ -129,7 +129,8 @@ int fvp_triplane_max(const float* cubes, float* planes, int nP, int J, int C, fv
  * (hipMemsetAsync); cross-workgroup maxima use integer atomicMax on the non-negative floats.
  * persons_per_frame > 0 promises person_frame[p] == p / persons_per_frame (placement hint: the
  * workgroups of one frame are numbered onto one XCD); pass 0 if unknown.
- * The heatmap footprint of every 8 x 4 x 32 voxel block is staged in LDS (LDS-DMA) and sampled from there.
+ * A workgroup owns a compact 4 x 4 x 16 voxel block; its taps are 16-byte global loads served by the CU's L1 (no LDS
+ * staging of the heatmap: DESIGN.md 4.1), LDS holds the block's plane maxima only.
  * fine_grid (may be NULL): the per-sequence cache of sampling coordinates the reference keeps
  * (project_individual.py:82-94), [nsets][V][fine0*fine1*fine2][2] as written by fvp_sample_grid on the fine
  * axes; when given, `fine` must point to the three fine-grid sizes in HOST memory and the kernel loads the
@@ -144,9 +145,12 @@ int fvp_project_individual_triplane(const float* heat_cl, const float* cams, con
  * A stack is a list of FvpConvOp over numbered activation buffers (all NCHW fp32,
  * [planes][C][H][W]; 1-D nets use H = 1).  The same interpreter runs CenterNet
  * (cnns_2d.py:147-178), C2CNet (cnns_1d.py:112-132) and P2PNet (cnns_2d.py:115-135).
- * Convs are implicit GEMMs on v_mfma_f32_32x32x2_f32; BatchNorm (eval) is applied in the
- * epilogue as  y = (acc + bias) * bn_scale + bn_shift  (no weight folding, to stay close to
- * the reference's rounding), followed by the optional residual add / ReLU. */
+ * Convs run on the fp32 matrix cores, the kernel chosen from the layer SHAPE alone (never the batch): 3x3 layers on
+ * power-of-two maps as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (k_conv_wino), P2PNet's 7x7 front conv on
+ * 16x16x4 tiles (k_conv7), 1x1 / transposed convs register-direct (k_conv_reg), everything else as implicit GEMMs on
+ * v_mfma_f32_32x32x2_f32 (k_conv_dma); the whole 1-D stack in one kernel (fvp_conv_stack_run_fused_1d).
+ * BatchNorm (eval) is applied in the epilogue as  y = (acc + bias) * bn_scale + bn_shift  (no weight folding, to stay
+ * close to the reference's rounding), followed by the optional residual add / ReLU. */
 enum {
   FVP_OP_CONV = 0,     /* stride-1 'same' conv, KH x KW                                     */
   FVP_OP_POOL2 = 1,    /* max_pool(2,2) (2-D) or max_pool1d(2) when H == 1                  */
@@ -218,11 +222,13 @@ int fvp_gather_proposals(const float* bbox_map, const float* cubes, const int64_
 /* ---- a-10/a-11: z arg-max, confidence product, proposal packing ---------------------------------
  * hm1d [B*N][Z]; idx2d from fvp_nms_topk.  topk_index [B][N][3] int64 (may be NULL);
  * centers [B][N][7] = (x,y,z mm = idx*scale + bias as fp32 mul then add, no FMA), valid-1,
- * conf, bbox_w, bbox_h.  sb = scale[3], bias[3].  Replaces human_detection_net.py:95-102 and
- * ProposalLayer.forward :44-65 (eval branch). */
+ * conf, bbox_w, bbox_h.  sb = scale[3], bias[3].  valid [B][N] uint8 (may be NULL) = centers[...,3] >= 0,
+ * the `mask` faster_voxelpose.py:45 hands to the joint localisation net (ABI 8: written here instead of by a
+ * separate comparison launch).  Replaces human_detection_net.py:95-102 and ProposalLayer.forward :44-65
+ * (eval branch). */
 int fvp_proposals(const float* hm1d, const float* conf2d, const int64_t* idx2d, const float* match_bbox,
                   const float* sb, float min_score, int B, int N, int Z, int64_t* topk_index, float* centers,
-                  fvp_stream_t s);
+                  uint8_t* valid, fvp_stream_t s);
 
 /* ---- a-11 standalone: ProposalLayer.forward, eval branch (human_detection_net.py:44-65) -----------
  * topk_index [B][N][3] int64 (voxel indices x, y, z), topk_confs [B][N], match_bbox [B][N][2];

@@ -46,6 +46,9 @@ def diag_lib():
 
     import torch  # noqa: F401  (its HIP runtime first: see _capi.load)
     from faster_voxelpose_amd import _capi as capi
+    marker = os.path.join(ROOT, "tests", "diag", "BUILD_FAILED")
+    if os.path.isfile(marker):          # written by __graft_entry__.build() when the -DFVP_DIAG=1 build broke
+        pytest.fail("the diagnostics library did not build in build():\n" + open(marker).read()[-2000:])
     if not os.path.isfile(_diag_path()):
         subprocess.run([os.path.join(ROOT, "tests", "diag", "build_diag.sh")], check=True, capture_output=True)
     lib = capi.bind(ctypes.CDLL(_diag_path()))

@@ -46,7 +46,7 @@ def zero_batch_through_every_export(lib, dev):
                                                                                     C.byref(g), p, N, None, s),
         "fvp_nms_topk": lambda: L.fvp_nms_topk(p, 0, X, Y, N, p, ip, ip, s),
         "fvp_gather_proposals": lambda: L.fvp_gather_proposals(p, p, ip, 0, J, X, Y, Z, N, p, p, p, s),
-        "fvp_proposals": lambda: L.fvp_proposals(p, p, ip, p, p, 0.1, 0, N, Z, ip, p, s),
+        "fvp_proposals": lambda: L.fvp_proposals(p, p, ip, p, p, 0.1, 0, N, Z, ip, p, None, s),
         "fvp_softargmax_weightnet": lambda: L.fvp_softargmax_weightnet(p, p, p, 100.0, 0, J, Cn, e.F, e.Hd, None, p, p, p, s),
         "fvp_fuse_poses": lambda: L.fvp_fuse_poses(p, p, p, p, None, 0, J, p, p, p, s),
         "fvp_rasterise_heatmaps": lambda: L.fvp_rasterise_heatmaps(p, ip, 0, 2, J, e.W, e.H, 4.0, 4.0, 3.0, p, None, e.JP, s),

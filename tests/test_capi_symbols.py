@@ -76,3 +76,10 @@ def test_state_dict_keys_match_reference_list():
     assert sd["joint_net.weight_net.output.2.weight"].shape == (1, 64)
     assert sum(v.numel() for k, v in sd.items() if not k.endswith("num_batches_tracked")
                and "running" not in k) > 2_600_000
+
+
+def test_diagnostics_build_did_not_fail_in_build():
+    """__graft_entry__.build() keeps a broken -DFVP_DIAG=1 build non-fatal for the product but leaves a marker; the CPU
+    suite fails on it, so a compile error that only shows in the diagnostics build is caught at build time."""
+    marker = os.path.join(ROOT, "tests", "diag", "BUILD_FAILED")
+    assert not os.path.isfile(marker), open(marker).read()[-2000:]

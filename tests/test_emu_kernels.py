@@ -316,8 +316,8 @@ def test_fused_projection_one_tile_two_tile_and_gather_rectangles(emu_lib, monke
         model.joint_net.fused_projection = True
         monkeypatch.setenv("FVP_TRI_CAP_PX", str(cap))
         monkeypatch.setenv("FVP_TRI_TWO_TILE", "1")
-        if quad:
-            monkeypatch.setenv("FVP_TRIPLANE_QUAD", "1")
+        # (the staged forms are diagnostics-build code since round 6: the emulator library is such a build)
+        monkeypatch.setenv("FVP_TRIPLANE_QUAD" if quad else "FVP_TRIPLANE_LANE", "1")
         model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
         got = model.engine.last_jln["planes"].clone()
     assert want.abs().sum() > 0 and torch.equal(got, want)
@@ -420,3 +420,43 @@ def test_front_conv7_random_shapes(emu_lib):
         keep = valid.bool()
         np.testing.assert_allclose(got[keep].double().numpy(), ref(x[keep]).numpy(), rtol=2e-5, atol=2e-5,
                                    err_msg=str((cin, h, w_, planes)))
+
+
+def test_validate_is_a_drop_in_for_the_reference_loop(emu_lib, tmp_path):
+    """core.function.validate with the reference's signature (lib/core/function.py:117: config, backbone, model, loader,
+    output_dir, has_evaluate_function) and loader protocol - 4-tuples (inputs, targets, meta, input_heatmaps), the dataset
+    carrying cameras / resize_transform / evaluate - exactly what run/validate.py:97-102 hands over.  Stub loader, the
+    real (emulated) hot path; the poses handed to dataset.evaluate equal the plain forward's, bit for bit."""
+    from faster_voxelpose_amd.core import function as FN
+    model, cfg, cams, seq, rt, heat, meta = build_model("tiny_g_b2_all", emu_lib)
+    with torch.no_grad():
+        want, _, _, _, _ = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
+    seen = {}
+
+    class Dataset:
+        cameras = cams
+        resize_transform = rt.numpy()
+
+        def evaluate(self, all_fused_poses):
+            seen["poses"] = all_fused_poses.clone()
+            return 12.5, "stub metric message"
+
+    class Loader:
+        dataset = Dataset()
+
+        def __len__(self):
+            return 2
+
+        def __iter__(self):
+            for _ in range(2):
+                yield torch.zeros(heat.shape[0], heat.shape[1], 3, 8, 8), None, meta, heat
+
+    cfg.DATASET.TEST_HEATMAP_SRC = "pred"                 # heatmaps come from the loader (function.py:142-148)
+    import types
+    cfg.TEST = types.SimpleNamespace(VISUALIZATION=False)
+    cfg.PRINT_FREQ = 1
+    assert FN.validate(cfg, None, model, Loader(), str(tmp_path), has_evaluate_function=False) == 0.0
+    metric = FN.validate(cfg, None, model, Loader(), str(tmp_path), has_evaluate_function=True)
+    assert metric == 12.5
+    assert seen["poses"].shape[0] == 2 * want.shape[0]
+    assert torch.equal(seen["poses"][:want.shape[0]], want) and torch.equal(seen["poses"][want.shape[0]:], want)

@@ -533,7 +533,7 @@ def test_rasteriser_vs_reference_golden(case):
 @pytest.mark.gpu
 def test_precomputed_heatmap_path_end_to_end_shelf():
     """BASELINE configs[2] shape (Shelf, 'pred' heatmap source): 2-D detections -> GPU rasteriser ->
-    hot path -> PCP evaluator, through core.function.validate; compared with the CPU oracle fed with
+    hot path -> PCP evaluator, through core.function.validate_batches; compared with the CPU oracle fed with
     the oracle's own rasterised heatmaps."""
     import functools
     import sys
@@ -555,7 +555,7 @@ def test_precomputed_heatmap_path_end_to_end_shelf():
     batches = [dict(meta={"seq": [seq, seq]}, pred_pose2d=[all_preds, all_preds]),
                dict(meta={"seq": [seq]}, pred_pose2d=[all_preds])]
     actors = [[np.random.default_rng(a).normal(0, 500, (14, 3)) for _ in range(3)] for a in range(4)]
-    metric, fused, info = FN.validate(cfg, model, batches, cams, rt, depth=2,
+    metric, fused, info = FN.validate_batches(cfg, model, batches, cams, rt, depth=2,
                                       evaluate=functools.partial(M.evaluate_pcp, actors_mm=actors))
     assert fused.shape == (3, cfg.CAPTURE_SPEC.MAX_PEOPLE, cfg.DATASET.NUM_JOINTS, 5) and info["frames"] == 3
     assert 0.0 <= metric <= 1.0 and set(info["evaluation"]) >= {"actor_pcp", "recall"}

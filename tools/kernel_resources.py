@@ -60,7 +60,24 @@ def _packed_between_mfma(co):
             before = any(0 < p - m <= 40 for m in mf)
             after = any(0 < m - p <= 40 for m in mf)
             near += bool(before and after)
-        res[name] = (len(mf), near)
+        # VALU-writes-SGPR -> VMEM hazard (5 wait states): the inline-asm buffer accesses are invisible to
+        # hipcc's hazard recognizer, so a v_readfirstlane whose SGPR is consumed by a buffer_* instruction among the next
+        # five instructions would go unnoticed.  Count them (the descriptors are re-pointed with SALU today: expected 0).
+        haz = 0
+        for i, ins_i in enumerate(ins):
+            m = re.match(r"v_readfirstlane_b32 s(\d+),", ins_i)
+            if not m:
+                continue
+            n = int(m.group(1))
+            for nxt in ins[i + 1:i + 6]:
+                if not nxt.startswith("buffer_"):
+                    continue
+                used = set()
+                for lo, hi in re.findall(r"s\[(\d+):(\d+)\]", nxt):
+                    used.update(range(int(lo), int(hi) + 1))
+                used.update(int(x) for x in re.findall(r"\bs(\d+)\b", nxt))
+                haz += n in used
+        res[name] = (len(mf), near, haz)
 
     for line in out.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -81,11 +98,11 @@ def scan_library(lib=DEFAULT_LIB):
         for co in _code_objects(lib, tmp):
             pk = _packed_between_mfma(co)
             for k in _metadata(co):
-                n_mfma, n_pk = pk.get(k["name"], (0, 0))
+                n_mfma, n_pk, n_haz = pk.get(k["name"], (0, 0, 0))
                 rows.append(dict(name=k["name"], vgpr=int(k.get("vgpr_count", 0)), agpr=int(k.get("agpr_count", 0)),
                                  sgpr=int(k.get("sgpr_count", 0)), sgpr_spill=int(k.get("sgpr_spill_count", 0)),
                                  vgpr_spill=int(k.get("vgpr_spill_count", 0)), scratch=int(k.get("private_segment_fixed_size", 0)),
-                                 mfma=n_mfma, packed_f32_between_mfma=n_pk))
+                                 mfma=n_mfma, packed_f32_between_mfma=n_pk, readfirstlane_to_buffer_hazards=n_haz))
     return rows
 
 
