@@ -629,6 +629,8 @@ k_bb_maxpool(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int N,
   *reinterpret_cast<Bf8*>(out + (size_t(n * OH + oy) * OW + ox) * C + g * 8) = o;
 }
 
+#include "fvp_backbone_fused.h"
+
 // Images NCHW fp32 [N][C<=4][H][W] -> NHWC bf16 with 4 channels per pixel (channel 3 zero for RGB).  Read as
 // [N][H][W/2][8] this is the input of the stem conv in its pixel-pair form (below).
 __global__ void __launch_bounds__(256)
@@ -754,6 +756,17 @@ extern "C" int fvp_bb_pack(const float* weight, const float* bias, const float* 
   return launch_status();
 }
 
+static int bb_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = cus;
+  }
+  return n;
+}
+
 template <int BN>
 static int bb_launch(const BbConvArgs& a, dim3 grid, hipStream_t s) {
   constexpr size_t lds_ab = (FVP_BB_NBUF * 128 * 72 + FVP_BB_NBUF * BN * 72) * sizeof(uint16_t) + 128;
@@ -787,9 +800,11 @@ struct BbSwitches {
   bool no_big;          // FVP_BB_NO_BIG: the register-staged kernel only
   int bn_cap;           // FVP_BB_DMA_BN: 128-cout tiles only
   bool no_fuse_final;   // FVP_BB_NO_FUSE_FINAL: heatmap layer as its own launch
+  bool no_fuse_stem;    // FVP_BB_NO_FUSE_STEM: stem conv and max-pool as two launches
   static BbSwitches read() {
     const char* bn = fvp::diag_env("FVP_BB_DMA_BN");
-    return {fvp::diag_env("FVP_BB_NO_BIG") != nullptr, bn ? atoi(bn) : 256, fvp::diag_env("FVP_BB_NO_FUSE_FINAL") != nullptr};
+    return {fvp::diag_env("FVP_BB_NO_BIG") != nullptr, bn ? atoi(bn) : 256, fvp::diag_env("FVP_BB_NO_FUSE_FINAL") != nullptr,
+            fvp::diag_env("FVP_BB_NO_FUSE_STEM") != nullptr};
   }
 };
 
@@ -855,6 +870,39 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
     }
     FVP_REQUIRE(op.kind == FVP_BB_CONV || op.kind == FVP_BB_DECONV);
     FVP_LIMIT(op.cinp >= 8 && (op.cinp & (op.cinp - 1)) == 0 && op.coutp % 64 == 0);
+    // stem conv + bn + ReLU + MaxPool2d(3, 2, 1) as one kernel (k_bb_stem_pool): the stem's output - the largest tensor of
+    // the network after the deconv head - is neither written nor read.  Eligible when the pooling is the only reader.
+    if ((op.flags & FVP_BB_STEM) && (op.flags & FVP_EPI_RELU) && !sw.no_fuse_stem && i + 1 < nops && op.res < 0 && op.dst >= 0 &&
+        op.coutp == 64 && op.cout == 64 && op.cinp == 8 && op.w % 2 == 0) {
+      const FvpBbOp& nx = ops[i + 1];
+      bool only_reader = nx.kind == FVP_BB_MAXPOOL && nx.src == op.dst && nx.cinp == 64 && nx.dst >= 0 && nx.h == op.oh && nx.w == op.ow &&
+                         nx.oh == (op.oh + 1) / 2 && nx.ow == (op.ow + 1) / 2;
+      for (int k = i + 2; k < nops && only_reader; ++k) only_reader = ops[k].src != op.dst && ops[k].res != op.dst;
+      if (only_reader && size_t(N) * op.h * op.w * 4 < (1u << 31)) {
+        BbStemArgs sa{};
+        sa.in = (const uint16_t*)bufs[op.src];
+        sa.out = (uint16_t*)bufs[nx.dst];
+        sa.w = wblob + op.w_off;
+        sa.epi = eblob + op.e_off;
+        sa.N = N;
+        sa.H = op.h;
+        sa.W2 = op.w / 2;
+        sa.CH = op.oh;
+        sa.CW = op.ow;
+        sa.PH = nx.oh;
+        sa.PW = nx.ow;
+        sa.tiles_x = ceil_div(nx.ow, kStQ);
+        sa.tiles_y = ceil_div(nx.oh, kStR);
+        sa.ntiles = sa.tiles_x * sa.tiles_y * N;
+        static LdsOptIn optin;
+        if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(&k_bb_stem_pool), kStLds)) return e;
+        hipLaunchKernelGGL(k_bb_stem_pool, dim3(unsigned(std::min(sa.ntiles, 2 * bb_num_cus()))), dim3(kStThreads), kStLds,
+                           as_stream(s), sa);
+        if (int rc = launch_status()) return rc;
+        ++i;
+        continue;
+      }
+    }
     BbConvArgs a{};
     a.in = (const uint16_t*)bufs[op.src];
     a.out = op.dst >= 0 ? (uint16_t*)bufs[op.dst] : nullptr;

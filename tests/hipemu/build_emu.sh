@@ -11,7 +11,7 @@ objs=()
 for s in fvp_capi fvp_project fvp_conv fvp_conv_wino fvp_conv1d_fused fvp_proposal fvp_joint fvp_heatmap fvp_backbone; do
   o="${here}/${s}.emu.o"
   if [[ ! -f "$o" || "$o" -ot "${csrc}/$s.hip" || "$o" -ot "${csrc}/fvp_common.h" || "$o" -ot "${csrc}/fvp_geom.h" \
-        || "$o" -ot "${here}/hip/hip_runtime.h" || "$o" -ot "${here}/../../include/fvp.h" || "$o" -ot "${csrc}/fvp_asm.h" || "$o" -ot "${csrc}/fvp_conv_args.h" || "$o" -ot "${csrc}/fvp_conv_reg.h" || "$o" -ot "${csrc}/fvp_project_lds.h" || "$o" -ot "${csrc}/fvp_conv7.h" ]]; then
+        || "$o" -ot "${here}/hip/hip_runtime.h" || "$o" -ot "${here}/../../include/fvp.h" || "$o" -ot "${csrc}/fvp_asm.h" || "$o" -ot "${csrc}/fvp_conv_args.h" || "$o" -ot "${csrc}/fvp_conv_reg.h" || "$o" -ot "${csrc}/fvp_project_lds.h" || "$o" -ot "${csrc}/fvp_conv7.h" || "$o" -ot "${csrc}/fvp_backbone_fused.h" ]]; then
     "$CXX" "${flags[@]}" -c "${csrc}/$s.hip" -o "$o" &
   fi
   objs+=("$o")

@@ -200,6 +200,24 @@ def test_backbone_emulated_matches_bf16_oracle(emu_lib):
     assert torch.equal(cl[..., :J], y.reshape(1, J, -1).permute(0, 2, 1)) and not cl[..., J:].any()
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (64, 96)])
+def test_backbone_fused_stem_pool_equals_the_two_launches(emu_lib, monkeypatch, hw):
+    """k_bb_stem_pool (conv1 + bn1 + ReLU + max-pool in one kernel, round 6) against the stem conv and the pooling as two
+    launches (FVP_BB_NO_FUSE_STEM=1, diagnostics build): the same MFMA chain per conv pixel, so the heatmaps must be
+    bit-equal - on an image smaller than one tile and on one with ragged tiles in both directions."""
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    cfg = CFG.default_config()
+    cfg.DEVICE = "cpu"
+    m = RN.PoseResNet(cfg, _lib=emu_lib)
+    m.load_state_dict(S.fill_backbone_state_dict(m.state_dict(), seed=5))
+    x = torch.from_numpy(np.random.default_rng(1).random((2, 3) + hw, dtype=np.float32))
+    fused = m(x)
+    monkeypatch.setenv("FVP_BB_NO_FUSE_STEM", "1")
+    two = m(x)
+    assert float(fused.abs().max()) > 0 and torch.equal(fused, two)
+
+
 def test_cached_fine_grid_gives_identical_planes(emu_lib):
     """The fused tri-plane kernel with the per-sequence coordinate cache (fine_grid) == recomputed projection."""
     case = "tiny_g_b2_all"

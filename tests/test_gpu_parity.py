@@ -701,6 +701,36 @@ def test_backbone_tile_shapes_give_identical_heatmaps(monkeypatch, diag_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 160, 224), (2, 512, 960), (1, 96, 64)])
+def test_backbone_fused_kernels_equal_the_separate_launches(monkeypatch, diag_lib, shape):
+    """Round 6: the stem conv + bn + ReLU + max-pool kernel (k_bb_stem_pool) and the fused bottleneck kernels against the
+    layer-by-layer launches they replace (FVP_BB_NO_FUSE_STEM / FVP_BB_NO_FUSE_BLOCK, diagnostics build).  Each fused
+    kernel runs the MFMA chain of the layers it replaces in the same k order and rounds to bf16 at the same points, so
+    the heatmaps are bit-equal - at the Panoptic image size, at a size with ragged tiles and on a small image."""
+    from faster_voxelpose_amd.core import config as CFG
+    from faster_voxelpose_amd.models import resnet as RN
+    cfg = CFG.default_config()
+    m = RN.PoseResNet(cfg, _lib=diag_lib).to("cuda:0")
+    m.load_state_dict(S.fill_backbone_state_dict(m.state_dict(), seed=5))
+    m.autotune = False
+    n, h, w = shape
+    x = torch.from_numpy(np.random.default_rng(4).random((n, 3, h, w), dtype=np.float32)).cuda()
+    with torch.no_grad():
+        fused = m(x).clone()
+        mp = RN.get(cfg).to("cuda:0")                      # the product library runs the fused kernels too: same bits
+        mp.load_state_dict(m.state_dict())
+        mp.autotune = False
+        assert torch.equal(mp(x), fused)
+        monkeypatch.setenv("FVP_BB_NO_FUSE_STEM", "1")
+        no_stem = m(x).clone()                             # stem + pooling as two launches, bottlenecks fused
+        monkeypatch.setenv("FVP_BB_NO_FUSE_BLOCK", "1")
+        plain = m(x).clone()                               # every layer its own launch
+    assert float(fused.abs().max()) > 0
+    assert torch.equal(fused, no_stem), ("stem", float((fused - no_stem).abs().max()))
+    assert torch.equal(fused, plain), ("bottleneck", float((fused - plain).abs().max()))
+
+
+@pytest.mark.gpu
 def test_backbone_tile_configurations_are_bit_identical_per_op():
     """fvp_bb_tune picks one of three tile configurations of the LDS-DMA conv kernel per op by timing them.  That is
     only legitimate if the choice cannot change a result: every eligible op of the Pose-ResNet-50 plan, run alone
