@@ -801,10 +801,11 @@ struct BbSwitches {
   int bn_cap;           // FVP_BB_DMA_BN: 128-cout tiles only
   bool no_fuse_final;   // FVP_BB_NO_FUSE_FINAL: heatmap layer as its own launch
   bool no_fuse_stem;    // FVP_BB_NO_FUSE_STEM: stem conv and max-pool as two launches
+  bool no_fuse_block;   // FVP_BB_NO_FUSE_BLOCK: layer1's bottlenecks layer by layer
   static BbSwitches read() {
     const char* bn = fvp::diag_env("FVP_BB_DMA_BN");
     return {fvp::diag_env("FVP_BB_NO_BIG") != nullptr, bn ? atoi(bn) : 256, fvp::diag_env("FVP_BB_NO_FUSE_FINAL") != nullptr,
-            fvp::diag_env("FVP_BB_NO_FUSE_STEM") != nullptr};
+            fvp::diag_env("FVP_BB_NO_FUSE_STEM") != nullptr, fvp::diag_env("FVP_BB_NO_FUSE_BLOCK") != nullptr};
   }
 };
 
@@ -847,6 +848,50 @@ static int bb_launch_conv(const FvpBbOp& op, BbConvArgs a, hipStream_t s, const 
   return wide ? bb_launch<128>(a, grid, s) : bb_launch<64>(a, grid, s);
 }
 
+// A 64-plane bottleneck at ops[i..]: [downsample 1x1 (no ReLU),] conv1 1x1 -> 64 + ReLU, conv2 3x3 s1 p1 64 -> 64 + ReLU,
+// conv3 1x1 64 -> 256 + residual + ReLU (resnet.py:57-95), all stride 1 on one map, the intermediates read by nobody else.
+// Returns the number of ops the fused kernel covers (0 = not this pattern).
+static int bb_match_bottleneck64(const FvpBbOp* ops, int nops, int i, int N) {
+  auto plain = [](const FvpBbOp& o, int k) {
+    return o.kind == FVP_BB_CONV && o.kh == k && o.kw == k && o.stride == 1 && o.pad == (k == 3 ? 1 : 0) && o.dst >= 0 &&
+           !(o.flags & (FVP_BB_STEM | FVP_BB_OUT_HEAT)) && o.cin == o.cinp && o.cout == o.coutp && o.cbuf == o.cout;
+  };
+  int j = i;
+  bool ds = false;
+  if (j + 3 < nops && plain(ops[j], 1) && !(ops[j].flags & FVP_EPI_RELU) && ops[j].res < 0 && ops[j].cout == 256 && ops[j].cin == 64 &&
+      ops[j + 1].src == ops[j].src && ops[j + 3].res == ops[j].dst) {
+    ds = true;
+    ++j;
+  }
+  if (j + 2 >= nops) return 0;
+  const FvpBbOp &c1 = ops[j], &c2 = ops[j + 1], &c3 = ops[j + 2];
+  if (!(plain(c1, 1) && plain(c2, 3) && plain(c3, 1))) return 0;
+  if (!((c1.flags & FVP_EPI_RELU) && (c2.flags & FVP_EPI_RELU) && (c3.flags & FVP_EPI_RELU))) return 0;
+  if (c1.cout != 64 || c2.cin != 64 || c2.cout != 64 || c3.cin != 64 || c3.cout != 256) return 0;
+  if (c1.res >= 0 || c2.res >= 0 || c2.src != c1.dst || c3.src != c2.dst) return 0;
+  if (c1.h != c2.h || c1.w != c2.w || c1.h != c3.h || c1.w != c3.w || c1.oh != c1.h || c1.ow != c1.w) return 0;
+  if (ds ? (c1.cin != 64 || c3.res != ops[i].dst || ops[i].h != c1.h || ops[i].w != c1.w)
+         : (c1.cin != 256 || c3.res != c1.src)) return 0;
+  if (c3.dst == c1.src) return 0;                                   // (the kernel reads neighbours' halos of x after writing its tile)
+  if (size_t(N) * c1.h * c1.w * 256 >= (size_t(1) << 31)) return 0;
+  // intermediates (and the downsample tensor) must have no other reader
+  const int n = j + 3 - i;
+  for (int k = i + n; k < nops; ++k)
+    for (int m = i; m < i + n - 1; ++m)
+      if (ops[k].src == ops[m].dst || ops[k].res == ops[m].dst) return 0;
+  return n;
+}
+
+template <int CIN, bool DS>
+static int bb_launch_bottleneck64(const BbBlockArgs& a, hipStream_t s) {
+  constexpr size_t lds = bb_block_lds(CIN, DS);
+  static LdsOptIn optin;
+  auto k = &k_bb_bottleneck64<CIN, DS>;
+  if (int e = lds_opt_in(optin, reinterpret_cast<const void*>(k), lds)) return e;
+  hipLaunchKernelGGL(k, dim3(unsigned(std::min(a.ntiles, bb_num_cus()))), dim3(kBkThreads), lds, s, a);
+  return launch_status();
+}
+
 extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs,
                           int nbufs, int N, float* heat_cl, int heat_jp, float* heat_nchw, fvp_stream_t s) {
   FVP_REQUIRE(ops && wblob && eblob && bufs && nops >= 0 && N >= 0);
@@ -870,6 +915,34 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
     }
     FVP_REQUIRE(op.kind == FVP_BB_CONV || op.kind == FVP_BB_DECONV);
     FVP_LIMIT(op.cinp >= 8 && (op.cinp & (op.cinp - 1)) == 0 && op.coutp % 64 == 0);
+    // a whole 64-plane bottleneck (layer1) as one kernel: k_bb_bottleneck64
+    if (!sw.no_fuse_block && !sw.no_big) {
+      if (const int nb = bb_match_bottleneck64(ops, nops, i, N)) {
+        const bool ds = nb == 4;
+        const FvpBbOp &c1 = ops[i + (ds ? 1 : 0)], &c2 = ops[i + (ds ? 2 : 1)], &c3 = ops[i + nb - 1];
+        for (int k = i; k < i + nb; ++k) FVP_REQUIRE(ops[k].src >= 0 && ops[k].src < nbufs && ops[k].dst < nbufs && ops[k].res < nbufs);
+        BbBlockArgs ba{};
+        ba.x = (const uint16_t*)bufs[c1.src];
+        ba.out = (uint16_t*)bufs[c3.dst];
+        ba.w1 = wblob + c1.w_off;
+        ba.w2 = wblob + c2.w_off;
+        ba.w3 = wblob + c3.w_off;
+        ba.wd = ds ? wblob + op.w_off : nullptr;
+        ba.e1 = eblob + c1.e_off;
+        ba.e2 = eblob + c2.e_off;
+        ba.e3 = eblob + c3.e_off;
+        ba.ed = ds ? eblob + op.e_off : nullptr;
+        ba.N = N;
+        ba.H = c1.h;
+        ba.W = c1.w;
+        ba.tiles_x = ceil_div(c1.w, kBkTW);
+        ba.tiles_y = ceil_div(c1.h, kBkTH);
+        ba.ntiles = ba.tiles_x * ba.tiles_y * N;
+        if (int rc = ds ? bb_launch_bottleneck64<64, true>(ba, as_stream(s)) : bb_launch_bottleneck64<256, false>(ba, as_stream(s))) return rc;
+        i += nb - 1;
+        continue;
+      }
+    }
     // stem conv + bn + ReLU + MaxPool2d(3, 2, 1) as one kernel (k_bb_stem_pool): the stem's output - the largest tensor of
     // the network after the deconv head - is neither written nor read.  Eligible when the pooling is the only reader.
     if ((op.flags & FVP_BB_STEM) && (op.flags & FVP_EPI_RELU) && !sw.no_fuse_stem && i + 1 < nops && op.res < 0 && op.dst >= 0 &&

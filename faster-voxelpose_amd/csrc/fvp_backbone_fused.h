@@ -144,3 +144,300 @@ __global__ void __launch_bounds__(kStThreads, 5) k_bb_stem_pool(BbStemArgs a) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_bb_bottleneck64<CIN, DS>: one layer1 Bottleneck (resnet.py:57-95) - conv1 1x1 CIN -> 64, conv2 3x3 64 -> 64,
+// conv3 1x1 64 -> 256, each with eval BN (+ ReLU), the residual (identity, or the 1x1 downsample conv + BN of the
+// stage's first block: DS) and the final ReLU - as ONE kernel.  As separate launches a block moved 2.5 GB for 40 images
+// (the 256-channel tensor is written once and read twice, the 64-channel intermediates written and read) at 660 us; fused
+// it reads x once (+ halo) and writes the output once: 1.26 GB.
+//   * persistent workgroups (one per CU, 8 waves, <= 256 VGPRs) walk tiles of 8 x 30 output pixels; the conv1 output t1
+//     is computed on the 10 x 32 halo (recomputed overlap 10/8 x 32/30) and kept in LDS as bf16, ZERO outside the image
+//     (conv2 pads t1, not x); t2 stays in LDS too; only the block's output goes to HBM;
+//   * every GEMM is v_mfma_f32_32x32x16_bf16 with the k order of the layer-by-layer kernels (ascending channels; conv2:
+//     taps outermost) and the same roundings (bf16 after each layer's BN / ReLU, the downsample branch rounded to bf16
+//     before it is added), so the block's output equals the separate launches bit for bit (tested on the GPU);
+//   * phase 1 (conv1): a wave owns a halo row; its B operand - 32 pixels x 16 channels per step - comes STRAIGHT from
+//     global memory (16 bytes per lane, a pixel's 128-byte line is consumed by four consecutive steps), W1 from LDS; the
+//     GEMM is transposed (A = weights) so a lane holds 4 consecutive couts of one pixel: 8-byte LDS writes of t1;
+//   * phase 2 (conv2): a wave owns two output rows x 32 couts; its 36 A operands (9 taps x 4 steps of W2) live in
+//     REGISTERS for the workgroup's whole life (144 VGPRs: W2 never touches LDS), B operands are tap-shifted rows of t1
+//     (ds_read_b128, XOR-swizzled 128-byte rows: conflict-free at any shift) - one LDS read per MFMA;
+//   * phase 3 (conv3 + residual): a wave owns an output row; A = t2 (a row's four operands stay in registers), B = W3 (LDS), 32 couts at a time; the epilogue is the
+//     one of k_bb_conv_dma (wave-private fp32 staging tile so that a lane stores 8 consecutive channels; 16-byte residual
+//     loads of x from L2 / Infinity Cache, where phase 1 left it).  DS: a second chain A = x (global), B = Wd on the same
+//     accumulator tile shape, rounded to bf16 like the stored downsample tensor, replaces the residual load.
+// LDS: t1 41 KB (reused as the staging tiles) + W1 32 KB (8 KB for CIN = 64) + t2 32 KB + W3 32 KB (+ Wd 32 KB) + BN
+// vectors 5 KB = 145 / 153 KB.  Columns 0 and 31 of a tile's 32-pixel rows are halo / garbage columns: computed, never
+// stored.
+// an opaque copy of a lane-derived value (defeats hoisting out of the persistent loop); the CPU emulator needs nothing
+#if defined(HIPEMU)
+#define FVP_OPAQUE_LANE(x) ((void)0)
+#else
+#define FVP_OPAQUE_LANE(x) asm volatile("" : "+v"(x) : : "memory")
+#endif
+constexpr int kBkTH = 8, kBkTW = 30;                // output rows / columns per tile
+constexpr int kBkHR = kBkTH + 2;                    // halo rows; halo columns: 32
+constexpr int kBkT1Rows = kBkHR * 32 + 2;           // + one guard pixel in front and behind (reached by the garbage columns only)
+constexpr int kBkThreads = 512;
+
+struct BbBlockArgs {
+  const uint16_t* x;        // [N][H][W][CIN] bf16
+  uint16_t* out;            // [N][H][W][256]
+  const uint16_t *w1, *w2, *w3, *wd;   // packed [cout][k] (k_bb_pack_w): [64][CIN], [64][9*64], [256][64], [256][CIN = 64]
+  const float *e1, *e2, *e3, *ed;      // scale | shift per layer
+  int N, H, W, tiles_x, tiles_y, ntiles;
+};
+
+constexpr size_t bb_block_lds(int cin, bool ds) {
+  return size_t(kBkT1Rows) * 128 + size_t(cin / 64) * 64 * 128 + 256 * 128 + 256 * 128 + (ds ? 256 * 128 : 0) + (128 + 128 + 512 + 512) * 4;
+}
+
+// 16-byte group g of the 128-byte row r sits at position g ^ ((r >> 1) & 7) (the swizzle of k_bb_conv_dma: conflict-free
+// operand fetches of 32 consecutive rows from any start row)
+__device__ __forceinline__ int bk_pos(int r, int g) { return r * 128 + ((g ^ ((r >> 1) & 7)) << 4); }
+
+template <int CIN, bool DS>
+__global__ void __launch_bounds__(kBkThreads, 2) k_bb_bottleneck64(BbBlockArgs a) {
+  static_assert(CIN % 64 == 0 && (!DS || CIN == 64), "the downsample form is the stage's first block (64 input channels)");
+  constexpr int NKB = CIN / 64;
+  HIP_DYNAMIC_SHARED(uint16_t, smem16)
+  char* T1 = reinterpret_cast<char*>(smem16);                     // [322][128 B]; phase 3: wave-private fp32 staging tiles
+  char* W1s = T1 + kBkT1Rows * 128;                               // [NKB][64 couts][128 B]
+  char* T2 = W1s + NKB * 64 * 128;                                // [8 x 32 pixels][128 B]
+  char* W3s = T2 + 256 * 128;                                     // [256 couts][128 B]
+  char* Wds = W3s + 256 * 128;                                    // [256 couts][128 B] (DS)
+  float* eps = reinterpret_cast<float*>(Wds + (DS ? 256 * 128 : 0));
+  const float* e1s = eps;                                         // scale[64] | shift[64]
+  const float* e2s = eps + 128;
+  const float* e3s = eps + 256;                                   // scale[256] | shift[256]
+  const float* eds = eps + 768;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31o = lane & 31, halfo = lane >> 5;
+
+  // ---- resident operands: W1 / W3 / Wd and the BN vectors in LDS, this wave's W2 operands in registers
+  for (int it = t; it < NKB * 64 * 8; it += kBkThreads) {
+    const int g = it & 7, r = (it >> 3) & 63, kb = it >> 9;
+    *reinterpret_cast<Bf8*>(W1s + kb * 64 * 128 + bk_pos(r, g)) = *reinterpret_cast<const Bf8*>(a.w1 + r * CIN + kb * 64 + g * 8);
+  }
+  for (int it = t; it < 256 * 8; it += kBkThreads) {
+    const int g = it & 7, r = it >> 3;
+    *reinterpret_cast<Bf8*>(W3s + bk_pos(r, g)) = *reinterpret_cast<const Bf8*>(a.w3 + r * 64 + g * 8);
+    if (DS) *reinterpret_cast<Bf8*>(Wds + bk_pos(r, g)) = *reinterpret_cast<const Bf8*>(a.wd + r * 64 + g * 8);
+  }
+  if (t < 128) {
+    eps[t] = a.e1[t];
+    eps[128 + t] = a.e2[t];
+  }
+  for (int i = t; i < 512; i += kBkThreads) {
+    eps[256 + i] = a.e3[i];
+    eps[768 + i] = DS ? a.ed[i] : 0.0f;
+  }
+  if (t < 16) {                                                   // the two guard pixels of t1 (finite values for the garbage columns)
+    reinterpret_cast<uint32_t*>(T1)[t] = 0u;
+    reinterpret_cast<uint32_t*>(T1 + (kBkT1Rows - 1) * 128)[t] = 0u;
+    reinterpret_cast<uint32_t*>(T1)[16 + t] = 0u;
+    reinterpret_cast<uint32_t*>(T1 + (kBkT1Rows - 1) * 128)[16 + t] = 0u;
+  }
+  const int cb2 = wave & 1, rp = wave >> 1;                       // phase 2: cout block, output row pair
+  Bf8 w2r[36];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      w2r[tap * 4 + ks] = *reinterpret_cast<const Bf8*>(a.w2 + (32 * cb2 + l31o) * 576 + tap * 64 + ks * 16 + halfo * 8);
+  __syncthreads();
+
+  for (int tid = blockIdx.x; tid < a.ntiles; tid += gridDim.x) {
+    const int tx = tid % a.tiles_x, r0 = tid / a.tiles_x, ty = r0 % a.tiles_y, n = r0 / a.tiles_y;
+    const int x0 = tx * kBkTW, y0 = ty * kBkTH;                   // first output pixel of the tile
+    // Lane-derived LDS / global offsets are recomputed per phase from an opaque copy of the lane id: they do not depend on
+    // the tile, so hipcc hoists all of them (~60 registers of swizzled addresses) out of the persistent loop and spills them
+    // beside the 144 registers of W2
+    int lane1 = lane;
+    FVP_OPAQUE_LANE(lane1);
+    const int l31 = lane1 & 31, half = lane1 >> 5;
+    const int gx = x0 - 1 + l31;                                  // this lane's pixel column in every 32-pixel row of the tile
+    const bool gx_in = unsigned(gx) < unsigned(a.W);
+    const int gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+
+    // ================= phase 1: t1 = relu(bn1(conv1(x))) on the halo, one halo row per wave
+    for (int hr = wave; hr < kBkHR; hr += 8) {
+      const int gy = y0 - 1 + hr;
+      const bool ok = gx_in && unsigned(gy) < unsigned(a.H);
+      const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+      const uint16_t* src = a.x + ((size_t(n) * a.H + gyc) * a.W + gxc) * CIN + half * 8;
+      f32x16 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+      Bf8 xa[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xa[0][ks] = *reinterpret_cast<const Bf8*>(src + ks * 16);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) xa[(kb + 1) & 1][ks] = *reinterpret_cast<const Bf8*>(src + (kb + 1) * 64 + ks * 16);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const Bf8 wa0 = *reinterpret_cast<const Bf8*>(W1s + kb * 64 * 128 + bk_pos(l31, 2 * ks + half));
+          const Bf8 wa1 = *reinterpret_cast<const Bf8*>(W1s + kb * 64 * 128 + bk_pos(32 + l31, 2 * ks + half));
+          acc[0] = mfma_bf16(wa0, xa[kb & 1][ks], acc[0]);
+          acc[1] = mfma_bf16(wa1, xa[kb & 1][ks], acc[1]);
+        }
+      }
+      const int row = 1 + hr * 32 + l31;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = 32 * cb + 8 * q + 4 * half;
+          const float4 sc = *reinterpret_cast<const float4*>(e1s + c0);
+          const float4 sh = *reinterpret_cast<const float4*>(e1s + 64 + c0);
+          const float v0 = fmaxf(acc[cb][4 * q + 0] * sc.x + sh.x, 0.0f), v1 = fmaxf(acc[cb][4 * q + 1] * sc.y + sh.y, 0.0f);
+          const float v2 = fmaxf(acc[cb][4 * q + 2] * sc.z + sh.z, 0.0f), v3 = fmaxf(acc[cb][4 * q + 3] * sc.w + sh.w, 0.0f);
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 o = {ok ? pack_bf16x2(v0, v1) : 0u, ok ? pack_bf16x2(v2, v3) : 0u};
+          *reinterpret_cast<u32x2*>(T1 + bk_pos(row, 4 * cb + q) + 8 * half) = o;
+        }
+    }
+    __syncthreads();
+
+    // ================= phase 2: t2 = relu(bn2(conv2(t1))): output rows 2 rp, 2 rp + 1 x couts [32 cb2, 32 cb2 + 32)
+    {
+      int lane2 = lane;
+      FVP_OPAQUE_LANE(lane2);
+      const int l31 = lane2 & 31, half = lane2 >> 5;
+      f32x16 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int rowa = 1 + (2 * rp + 1 + dy) * 32 + l31 + dx;   // t1 row of output row 2 rp under this tap
+        const int sw = (rowa >> 1) & 7;                           // (+ 32 rows: the same swizzle)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int off = rowa * 128 + (((2 * ks + half) ^ sw) << 4);
+          const Bf8 b0 = *reinterpret_cast<const Bf8*>(T1 + off);
+          const Bf8 b1 = *reinterpret_cast<const Bf8*>(T1 + off + 32 * 128);
+          acc[0] = mfma_bf16(w2r[tap * 4 + ks], b0, acc[0]);
+          acc[1] = mfma_bf16(w2r[tap * 4 + ks], b1, acc[1]);
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = (2 * rp + rr) * 32 + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = 32 * cb2 + 8 * q + 4 * half;
+          const float4 sc = *reinterpret_cast<const float4*>(e2s + c0);
+          const float4 sh = *reinterpret_cast<const float4*>(e2s + 64 + c0);
+          const float v0 = fmaxf(acc[rr][4 * q + 0] * sc.x + sh.x, 0.0f), v1 = fmaxf(acc[rr][4 * q + 1] * sc.y + sh.y, 0.0f);
+          const float v2 = fmaxf(acc[rr][4 * q + 2] * sc.z + sh.z, 0.0f), v3 = fmaxf(acc[rr][4 * q + 3] * sc.w + sh.w, 0.0f);
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+          *reinterpret_cast<u32x2*>(T2 + bk_pos(row, 4 * cb2 + q) + 8 * half) = o;
+        }
+      }
+    }
+    __syncthreads();                                              // t2 complete; t1 is dead: its memory becomes the staging tiles
+
+    // ================= phase 3: out = relu(bn3(conv3(t2)) + residual), output row `wave`, 32 couts at a time
+    {
+      // (everything of this phase is derived from an opaque copy of the lane id: hipcc otherwise computes the epilogue's
+      // addresses in front of phase 2 and spills them across it - 40 VGPRs beside the 144 of W2)
+      int lane3 = lane;
+      FVP_OPAQUE_LANE(lane3);
+      const int gy = y0 + wave;
+      constexpr int EP = 32 + 4;
+      float* et = reinterpret_cast<float*>(T1) + wave * (32 * EP);
+      // this lane's two (pixel, 8-channel group) vectors of a 32 x 32 block: pixel = idx >> 2, group = idx & 3
+      size_t pixv[2];
+      bool okv[2];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int pc = (lane3 + 64 * v) >> 2;                     // pixel column inside the tile row
+        const int px = x0 - 1 + pc;
+        okv[v] = pc >= 1 && pc <= kBkTW && px < a.W && gy < a.H;
+        pixv[v] = ((size_t(n) * a.H + (gy < a.H ? gy : a.H - 1)) * a.W + (okv[v] ? px : 0)) * 256;
+      }
+      const int gyc = gy < a.H ? gy : a.H - 1;
+      const int l31c = lane3 & 31, halfc = lane3 >> 5;
+      const int t2row = wave * 32 + l31c;
+      const int t2sw = (t2row >> 1) & 7;
+      // A operands of the row: t2 (and, DS, the row's x pixels for the downsample chain) - loaded once, used for all 8 cout blocks
+      Bf8 ta[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ta[ks] = *reinterpret_cast<const Bf8*>(T2 + t2row * 128 + (((2 * ks + halfc) ^ t2sw) << 4));
+      [[maybe_unused]] Bf8 xd[4];
+      if (DS) {
+        const int gx3 = x0 - 1 + l31c, gxc3 = gx3 < 0 ? 0 : (gx3 >= a.W ? a.W - 1 : gx3);
+        const uint16_t* xs = a.x + ((size_t(n) * a.H + gyc) * a.W + gxc3) * CIN + halfc * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xd[ks] = *reinterpret_cast<const Bf8*>(xs + ks * 16);
+      }
+#pragma unroll 1
+      for (int cb = 0; cb < 8; ++cb) {
+        const int cj = 32 * cb;
+        const int wrow = cj + l31c;
+        const int wsw = (wrow >> 1) & 7;
+        const int co = cj + (lane3 & 3) * 8;
+        Bf8 resv[2];
+        if (!DS) {                                                // residual = x: requested before the MFMAs
+#pragma unroll
+          for (int v = 0; v < 2; ++v) resv[v] = *reinterpret_cast<const Bf8*>(a.x + pixv[v] + co);
+        }
+        f32x16 acc;
+        [[maybe_unused]] f32x16 accd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        if (DS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            accd = mfma_bf16(xd[ks], *reinterpret_cast<const Bf8*>(Wds + wrow * 128 + (((2 * ks + halfc) ^ wsw) << 4)), accd);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          acc = mfma_bf16(ta[ks], *reinterpret_cast<const Bf8*>(W3s + wrow * 128 + (((2 * ks + halfc) ^ wsw) << 4)), acc);
+        const float sc = e3s[cj + l31c], sh = e3s[256 + cj + l31c];
+        [[maybe_unused]] const float scd = eds[cj + l31c], shd = eds[256 + cj + l31c];
+        __builtin_amdgcn_wave_barrier();                          // the previous block's readers are done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[r] * sc + sh;
+          if (DS) v += bf2f(f2bf(accd[r] * scd + shd));           // the downsample tensor as it would have been stored (bf16)
+          et[((r & 3) + 8 * (r >> 2) + 4 * halfc) * EP + l31c] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // own LDS writes landed (wave-private tile)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int idx = lane3 + 64 * v, row = idx >> 2, g = idx & 3;
+          const float4 lo = *reinterpret_cast<const float4*>(et + row * EP + g * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(et + row * EP + g * 8 + 4);
+          float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          Bf8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v0 = xv[2 * e], v1 = xv[2 * e + 1];
+            if (!DS) {
+              v0 += bf2f(uint16_t(resv[v].w[e] & 0xffffu));
+              v1 += bf2f(uint16_t(resv[v].w[e] >> 16));
+            }
+            o.w[e] = pack_bf16x2(fmaxf(v0, 0.0f), fmaxf(v1, 0.0f));
+          }
+          if (okv[v]) *reinterpret_cast<Bf8*>(a.out + pixv[v] + co) = o;
+        }
+      }
+    }
+    __syncthreads();                                              // staging tiles (t1's memory) and t2 are free for the next tile
+  }
+}

@@ -216,6 +216,11 @@ def test_backbone_fused_stem_pool_equals_the_two_launches(emu_lib, monkeypatch, 
     monkeypatch.setenv("FVP_BB_NO_FUSE_STEM", "1")
     two = m(x)
     assert float(fused.abs().max()) > 0 and torch.equal(fused, two)
+    # ... and layer1's bottlenecks (k_bb_bottleneck64, with and without the downsample branch) against the layer-by-layer
+    # launches: the same chains and roundings, bit-equal
+    monkeypatch.setenv("FVP_BB_NO_FUSE_BLOCK", "1")
+    plain = m(x)
+    assert torch.equal(fused, plain), float((fused - plain).abs().max())
 
 
 def test_cached_fine_grid_gives_identical_planes(emu_lib):

@@ -34,21 +34,48 @@ def per_op(m, x, a):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot = 0.0
     ops = plan["tuned"].get(N, plan["ops"])               # the tile configurations fvp_bb_tune picked, if it ran
-    for i, op in enumerate(ops):
-        one = (capi.FvpBbOp * 1)(op)
+    # launch groups: ops the library fuses into one kernel are timed together (stem + max-pool; a layer1 bottleneck =
+    # [downsample,] conv1, conv2, conv3), everything else one op at a time
+    groups, i = [], 0
+    while i < len(ops):
+        n = 1
+        if a.fused_groups:
+            if (ops[i].flags & capi.BB_STEM) and i + 1 < len(ops) and ops[i + 1].kind == capi.BB_MAXPOOL:
+                n = 2
+            else:
+                j = i + 1 if (ops[i].kind == 0 and ops[i].kh == 1 and i + 3 < len(ops) and ops[i + 1].src == ops[i].src
+                              and ops[i + 3].res == ops[i].dst) else i      # downsample in front of the block
+                if (j + 2 < len(ops) and ops[j].kind == 0 and ops[j].kh == 1 and ops[j].cout == 64 and ops[j + 1].kh == 3
+                        and ops[j + 1].stride == 1 and ops[j + 1].src == ops[j].dst and ops[j + 2].kh == 1
+                        and ops[j + 2].src == ops[j + 1].dst and ops[j + 2].cout == 256):
+                    n = j + 3 - i
+        groups.append((i, n))
+        i += n
+    for i, n in groups:
+        op = ops[i + n - 1] if n > 1 else ops[i]
+        one = (capi.FvpBbOp * n)(*ops[i:i + n])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(4):
             if it == 1:
                 e0.record()
-            rc = m.lib.fvp_bb_run(one, 1, C.c_void_p(m._wblob.data_ptr()), C.c_void_p(m._eblob.data_ptr()), arr, len(bufs), N,
+            rc = m.lib.fvp_bb_run(one, n, C.c_void_p(m._wblob.data_ptr()), C.c_void_p(m._eblob.data_ptr()), arr, len(bufs), N,
                                   C.c_void_p(cl.data_ptr()), 16, None, s)
             assert rc == 0, rc
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 3
         tot += us
-        fl = 0.0 if op.kind == 1 else 2.0 * op.cin * op.cout * (4 if op.kind == 2 else op.kh * op.kw) * op.oh * op.ow * N
-        by = 2.0 * N * (op.cinp * op.h * op.w + op.cout * op.oh * op.ow * (2 if op.res >= 0 else 1))
+        fl = sum(0.0 if o.kind == 1 else 2.0 * o.cin * o.cout * (4 if o.kind == 2 else o.kh * o.kw) * o.oh * o.ow * N
+                 for o in ops[i:i + n])
+        first = ops[i]
+        if n == 1:
+            by = 2.0 * N * (op.cinp * op.h * op.w + op.cout * op.oh * op.ow * (2 if op.res >= 0 else 1))
+        else:   # fused group: its input once, its output once (the identity residual IS the input)
+            by = 2.0 * N * (first.cinp * first.h * first.w + op.cout * op.oh * op.ow)
+        if n > 1:
+            print(f"  op{i:2d}-{i + n - 1:2d} fused group of {n}: {first.cin:4d}->{op.cout:4d} @{first.h}x{first.w} -> {op.oh}x{op.ow}  "
+                  f"{us:8.1f} us  {fl / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s (algorithmic in + out)")
+            continue
         print(f"  op{i:2d} kind {op.kind} cfg {(op.flags >> 8) & 3} {op.cin:4d}->{op.cout:4d} k{op.kh} s{op.stride} @{op.h}x{op.w}  {us:8.1f} us  "
               f"{fl / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s")
     print(f"  total {tot / 1e3:.2f} ms")
@@ -61,6 +88,8 @@ def main():
     ap.add_argument("--h", type=int, default=512)
     ap.add_argument("--w", type=int, default=960)
     ap.add_argument("--per-op", action="store_true")
+    ap.add_argument("--no-fused-groups", dest="fused_groups", action="store_false",
+                    help="--per-op: time every op alone (the fused kernels then never run)")
     a = ap.parse_args()
     cfg = CFG.default_config()
     m = RN.get(cfg).to("cuda:0")
