@@ -802,10 +802,12 @@ struct BbSwitches {
   bool no_fuse_final;   // FVP_BB_NO_FUSE_FINAL: heatmap layer as its own launch
   bool no_fuse_stem;    // FVP_BB_NO_FUSE_STEM: stem conv and max-pool as two launches
   bool no_fuse_block;   // FVP_BB_NO_FUSE_BLOCK: layer1's bottlenecks layer by layer
+  int ablate;           // FVP_BB_ABLATE: phase ablations of k_bb_bottleneck64 (wrong results)
   static BbSwitches read() {
     const char* bn = fvp::diag_env("FVP_BB_DMA_BN");
     return {fvp::diag_env("FVP_BB_NO_BIG") != nullptr, bn ? atoi(bn) : 256, fvp::diag_env("FVP_BB_NO_FUSE_FINAL") != nullptr,
-            fvp::diag_env("FVP_BB_NO_FUSE_STEM") != nullptr, fvp::diag_env("FVP_BB_NO_FUSE_BLOCK") != nullptr};
+            fvp::diag_env("FVP_BB_NO_FUSE_STEM") != nullptr, fvp::diag_env("FVP_BB_NO_FUSE_BLOCK") != nullptr,
+            fvp::diag_env("FVP_BB_ABLATE") ? atoi(fvp::diag_env("FVP_BB_ABLATE")) : 0};
   }
 };
 
@@ -938,6 +940,7 @@ extern "C" int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, c
         ba.tiles_x = ceil_div(c1.w, kBkTW);
         ba.tiles_y = ceil_div(c1.h, kBkTH);
         ba.ntiles = ba.tiles_x * ba.tiles_y * N;
+        ba.ablate = int(sw.ablate);
         if (int rc = ds ? bb_launch_bottleneck64<64, true>(ba, as_stream(s)) : bb_launch_bottleneck64<256, false>(ba, as_stream(s))) return rc;
         i += nb - 1;
         continue;

@@ -20,6 +20,14 @@
 //     outputs are >= 0, so 0 is the identity of the maximum (MaxPool2d pads with -inf); non-negative bf16 order like
 //     unsigned integers, so the 3 x 3 maximum is v_pk_max_u16 on the packed pairs;
 //   * the next tile's input patch is requested into registers before this tile's MFMAs.
+// workgroup barrier for LDS hand-overs: this wave's LDS operations have completed (lgkmcnt(0)) - and nothing else is
+// waited for.  __syncthreads() is fence + barrier and the fence drains the wave's outstanding global STORES too (vmcnt(0)):
+// every phase boundary would wait for the acknowledgements of the previous tile's output stores.
+__device__ __forceinline__ void bk_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+}
+
 constexpr int kStR = 4, kStQ = 15;                  // pooled rows / columns per tile
 constexpr int kStCR = 2 * kStR + 1, kStCC = 32;     // conv rows / columns per tile (column 31 is computed, never used)
 constexpr int kStIR = 2 * kStCR + 5;                // input rows of the patch: 23
@@ -71,11 +79,12 @@ __global__ void __launch_bounds__(kStThreads, 5) k_bb_stem_pool(BbStemArgs a) {
       if (!ok) pre[u] = Bf8{{0u, 0u, 0u, 0u}};
     }
   };
+  __syncthreads();                                       // weights and BN vectors are in LDS
   int tid = blockIdx.x;
   if (tid < a.ntiles) request(tid);
   for (; tid < a.ntiles; tid += gridDim.x) {
     const int tx = tid % a.tiles_x, r0 = tid / a.tiles_x, ty = r0 % a.tiles_y, n = r0 / a.tiles_y;
-    __syncthreads();                                     // the previous tile's pooling has read the conv tile (same memory)
+    bk_barrier();                                        // the previous tile's pooling has read the conv tile (same memory)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int it = t + u * kStThreads;
@@ -84,7 +93,7 @@ __global__ void __launch_bounds__(kStThreads, 5) k_bb_stem_pool(BbStemArgs a) {
         *reinterpret_cast<Bf8*>(tile + (ar * kStIP + b) * 8) = pre[u];
       }
     }
-    __syncthreads();
+    bk_barrier();   
     if (tid + int(gridDim.x) < a.ntiles) request(tid + int(gridDim.x));
 
     // ---- conv row `wave` of the tile: D[cout][pixel] over K = 224 in 14 steps (kh = s >> 1, pair taps 2 (s & 1) + half)
@@ -103,7 +112,7 @@ __global__ void __launch_bounds__(kStThreads, 5) k_bb_stem_pool(BbStemArgs a) {
       acc[0] = mfma_bf16(w0, xb, acc[0]);
       acc[1] = mfma_bf16(w1, xb, acc[1]);
     }
-    __syncthreads();                                     // every wave has read the patch: the conv tile may overwrite it
+    bk_barrier();                                        // every wave has read the patch: the conv tile may overwrite it
 
     // ---- BN + ReLU, 0 outside the image, bf16, this lane's pixel (wave, l31): 8 quads of 4 consecutive couts
     {
@@ -124,7 +133,7 @@ __global__ void __launch_bounds__(kStThreads, 5) k_bb_stem_pool(BbStemArgs a) {
           *reinterpret_cast<u32x2*>(dst + c0) = o;
         }
     }
-    __syncthreads();
+    bk_barrier();   
 
     // ---- 3 x 3 / 2 maximum: thread = (pooled row r, pooled column q, 8-channel group g)
     if (t < kStR * kStQ * 8) {
@@ -187,6 +196,7 @@ struct BbBlockArgs {
   const uint16_t *w1, *w2, *w3, *wd;   // packed [cout][k] (k_bb_pack_w): [64][CIN], [64][9*64], [256][64], [256][CIN = 64]
   const float *e1, *e2, *e3, *ed;      // scale | shift per layer
   int N, H, W, tiles_x, tiles_y, ntiles;
+  int ablate;               // diagnostics build only (FVP_BB_ABLATE, wrong results): 1 no residual loads, 2 no stores, 4 x from one pixel (L1 hits)
 };
 
 constexpr size_t bb_block_lds(int cin, bool ds) {
@@ -267,6 +277,9 @@ __global__ void __launch_bounds__(kBkThreads, 2) k_bb_bottleneck64(BbBlockArgs a
       const bool ok = gx_in && unsigned(gy) < unsigned(a.H);
       const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
       const uint16_t* src = a.x + ((size_t(n) * a.H + gyc) * a.W + gxc) * CIN + half * 8;
+#if FVP_DIAG
+      if (a.ablate & 4) src = a.x + half * 8;
+#endif
       f32x16 acc[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -304,7 +317,7 @@ __global__ void __launch_bounds__(kBkThreads, 2) k_bb_bottleneck64(BbBlockArgs a
           *reinterpret_cast<u32x2*>(T1 + bk_pos(row, 4 * cb + q) + 8 * half) = o;
         }
     }
-    __syncthreads();
+    bk_barrier();
 
     // ================= phase 2: t2 = relu(bn2(conv2(t1))): output rows 2 rp, 2 rp + 1 x couts [32 cb2, 32 cb2 + 32)
     {
@@ -346,7 +359,7 @@ __global__ void __launch_bounds__(kBkThreads, 2) k_bb_bottleneck64(BbBlockArgs a
         }
       }
     }
-    __syncthreads();                                              // t2 complete; t1 is dead: its memory becomes the staging tiles
+    bk_barrier();                                                 // t2 complete; t1 is dead: its memory becomes the staging tiles
 
     // ================= phase 3: out = relu(bn3(conv3(t2)) + residual), output row `wave`, 32 couts at a time
     {
@@ -382,6 +395,18 @@ __global__ void __launch_bounds__(kBkThreads, 2) k_bb_bottleneck64(BbBlockArgs a
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xd[ks] = *reinterpret_cast<const Bf8*>(xs + ks * 16);
       }
+      // residual = x (identity blocks): the loads of cout block cb + 1 are issued BEFORE the stores of block cb - vmcnt
+      // retires in order, so a load queued behind stores would wait for their acknowledgements (measured: ~100 us per launch)
+      Bf8 resn[2];
+      auto request_res = [&](int cb_) {
+#if FVP_DIAG
+        resn[0] = resn[1] = Bf8{{0u, 0u, 0u, 0u}};
+        if (a.ablate & 1) return;
+#endif
+#pragma unroll
+        for (int v = 0; v < 2; ++v) resn[v] = *reinterpret_cast<const Bf8*>(a.x + pixv[v] + 32 * cb_ + (lane3 & 3) * 8);
+      };
+      if (!DS) request_res(0);
 #pragma unroll 1
       for (int cb = 0; cb < 8; ++cb) {
         const int cj = 32 * cb;
@@ -389,9 +414,10 @@ __global__ void __launch_bounds__(kBkThreads, 2) k_bb_bottleneck64(BbBlockArgs a
         const int wsw = (wrow >> 1) & 7;
         const int co = cj + (lane3 & 3) * 8;
         Bf8 resv[2];
-        if (!DS) {                                                // residual = x: requested before the MFMAs
-#pragma unroll
-          for (int v = 0; v < 2; ++v) resv[v] = *reinterpret_cast<const Bf8*>(a.x + pixv[v] + co);
+        if (!DS) {
+          resv[0] = resn[0];
+          resv[1] = resn[1];
+          if (cb + 1 < 8) request_res(cb + 1);
         }
         f32x16 acc;
         [[maybe_unused]] f32x16 accd;
@@ -434,10 +460,13 @@ __global__ void __launch_bounds__(kBkThreads, 2) k_bb_bottleneck64(BbBlockArgs a
             }
             o.w[e] = pack_bf16x2(fmaxf(v0, 0.0f), fmaxf(v1, 0.0f));
           }
+#if FVP_DIAG
+          if ((a.ablate & 2) && o.w[0] != 0x12345678u) continue;
+#endif
           if (okv[v]) *reinterpret_cast<Bf8*>(a.out + pixv[v] + co) = o;
         }
       }
     }
-    __syncthreads();                                              // staging tiles (t1's memory) and t2 are free for the next tile
+    bk_barrier();                                                 // staging tiles (t1's memory) and t2 are free for the next tile
   }
 }
