@@ -35,6 +35,9 @@ FP64_EXCEPTIONS = {"tiny_u_b3_thr": 3e-3, "campus_u_b2_all": 4e-3, "panoptic_u_b
 # (tighter than the triangle inequality K64 + 1 = 2.5, and than the seed sweep's R2 factor 3).  Fixed before the first GPU
 # run of this fixture; the CPU emulation of the kernels gave worst ratios 1.26 / 1.71 (9 proposals, pfloor 0.96e-3 .. 1.97e-3,
 # |build - ref32| max 2.0e-3 mm: the literal 1e-3 mm bar is NOT met on Campus, by the reference's fp32 path either).
+# Round 6: K32 is no longer only a chosen constant - the reference run against ITSELF with another conv summation order
+# (tests/golden/reorder_distribution.json, make_reorder_distribution.py) lands up to 1.62 x a Campus proposal's own floor
+# from its fp32 result (p95 1.38, 100 of 100 proposals within 2 x): K32 = 2.0 = 1.25 x that maximum, rounded.
 FLOOR_RULE = {"campus_c_b2_thr": (1.5, 2.0)}
 FLOOR_RULE_ABS_MM = 2.5e-3
 
@@ -59,6 +62,57 @@ def floor_rule_check(case, xyz, g, report=None):
     assert r64.max() <= k64 and r32.max() <= k32, \
         f"{case}: |build-ref64| / pfloor max {r64.max():.2f} (bar {k64}), |build-ref32| / pfloor max {r32.max():.2f} (bar {k32})"
     return float(r64.max()), float(r32.max())
+
+
+# ---- drift gate ---------------------------------------------------------------------------
+# tests/golden/parity_baseline.json holds the float results of the HIP path on the MI355X as they are at the commit it names.
+# The kernels are deterministic, so an unchanged build reproduces them exactly on any box; a change of a summation order
+# moves them.  Nothing used to fail until the 1e-3 mm bar itself (Shelf went 3.1e-4 -> 4.3e-4 mm in round 5 unnoticed in the
+# documents): now a fixture / sweep figure that GROWS past the tolerance below fails the GPU suite unless the baseline file
+# is updated in the same commit (tools/update_parity_baseline.py) - the drift is then visible in the diff.
+DRIFT_TOL = 1.10            # a tracked maximum may grow by 10 % before the baseline has to be re-pinned
+DRIFT_FLOOR_FACTOR = 1.5    # conditioned Panoptic / Shelf fixtures: |build - ref32| max <= 1.5 x the reference's own fp32-vs-fp64 floor
+DRIFT_FRAC_TOL = 0.003      # fraction of sweep joints within 1e-3 mm may drop by 0.3 points
+
+
+def parity_baseline():
+    import json
+    with open(os.path.join(GOLDEN_DIR, "parity_baseline.json")) as f:
+        return json.load(f)
+
+
+def drift_check(kind, name, rep):
+    """kind = 'fixtures' (rep of check_outputs) or 'sweeps' (summary of seed_sweep.replay).  Returns the findings; the
+    callers assert that the list is empty."""
+    base = parity_baseline()[kind].get(name)
+    if base is None:
+        return [f"{name}: no entry in tests/golden/parity_baseline.json (run tools/update_parity_baseline.py)"]
+    bad = []
+
+    def grew(key, tol=DRIFT_TOL):
+        if key in base and key in rep and rep[key] > tol * base[key] + 1e-12:
+            bad.append(f"{name}: {key} {rep[key]:.4g} > {tol:.2f} x baseline {base[key]:.4g}")
+
+    if kind == "fixtures":
+        grew("max_mm_vs_fp64")
+        if is_conditioned(name):
+            grew("max_mm_vs_ref")
+            if name not in FLOOR_RULE and rep["max_mm_vs_ref"] > DRIFT_FLOOR_FACTOR * rep["ref_floor_mm"] + 1e-12:
+                bad.append(f"{name}: max_mm_vs_ref {rep['max_mm_vs_ref']:.3e} > {DRIFT_FLOOR_FACTOR} x the reference's own floor "
+                           f"{rep['ref_floor_mm']:.3e}")
+            for key in ("worst_ratio_vs_fp64", "worst_ratio_vs_ref32"):
+                grew(key)
+    else:
+        for key in ("max_mm_r1q", "max_mm_where_floor_le_4e-4", "worst_err_over_proposal_floor", "worst_proposal_err_over_own_floor"):
+            grew(key)
+        if rep.get("violations_where_floor_le_4e-4", 0) > base.get("violations_where_floor_le_4e-4", 0):
+            bad.append(f"{name}: literal-R1 violations {rep['violations_where_floor_le_4e-4']} > baseline {base['violations_where_floor_le_4e-4']}")
+        if rep["frac_within_1e-3_mm"] < base["frac_within_1e-3_mm"] - DRIFT_FRAC_TOL:
+            bad.append(f"{name}: fraction of joints within 1e-3 mm {rep['frac_within_1e-3_mm']:.4f} < baseline "
+                       f"{base['frac_within_1e-3_mm']:.4f} - {DRIFT_FRAC_TOL}")
+        if rep["joints"] != base["joints"] or rep["proposals"] != base["proposals"]:
+            bad.append(f"{name}: compared {rep['joints']} joints / {rep['proposals']} proposals, baseline {base['joints']} / {base['proposals']}")
+    return bad
 
 
 def is_conditioned(case):

@@ -201,6 +201,21 @@ def replay(name, dev, seeds=None, detail_path=None):
     return s, rows
 
 
+def measured_factors(name):
+    """The reference's own spread under another conv summation order for this sweep (reorder_distribution.json, made by
+    make_reorder_distribution.py in the build container): worst per-joint ratio to max(proposal floor, 4e-4) - the quantity
+    R2 bounds -, worst per-proposal ratio to the proposal's own floor and the fraction of proposals within 2 x of it."""
+    import json
+    with open(os.path.join(HERE, "reorder_distribution.json")) as f:
+        allsw = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+    d = allsw[name]
+    # R2's factor is pooled over the sweeps: the per-sweep maximum of a few hundred proposals is itself a noisy sample (the
+    # three-seed B = 32 leg shows 1.36 where the ten-seed B = 8 leg of the same shape shows 1.73)
+    return {"joint_ratio_max": max(v["joint_ratio_r2"]["max"] for v in allsw.values()),
+            "proposal_ratio_max": d["proposal_ratio"]["max"],
+            "frac_within_2x": d["proposals_within_2x_own_floor"] / max(d["proposals"], 1)}
+
+
 def replay_all(dev):
     """bench.py's mpjpe_vs_ref_mm.all entries: every sweep shape present on disk."""
     out = {}

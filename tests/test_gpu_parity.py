@@ -10,7 +10,7 @@ import torch
 
 import fvp_oracle as O
 from cases import CASES, make_inputs, make_weights
-from common import check_outputs, front7_stack, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
+from common import check_outputs, drift_check, front7_stack, load_golden, reg_stack, run_custom_conv_stack, split_k_stack
 import fvp_synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +49,10 @@ def test_golden_case(case):
         check_outputs(case, g, f2, p2, c2, model.engine)
         assert torch.equal(model.engine.last["feat1d"], feat1d)
         assert torch.equal(fused, f2) and torch.equal(planes, p2) and torch.equal(centers, c2)
+        # drift gate: the fixture's float figures against tests/golden/parity_baseline.json (common.drift_check)
+        bad = drift_check("fixtures", case, report)
+        assert not bad, "float parity drifted past the pinned baseline (re-pin with tools/update_parity_baseline.py " \
+                        "in the same commit if intended): " + "; ".join(bad)
     finally:
         os.makedirs(os.path.dirname(REPORT), exist_ok=True)
         with open(REPORT, "a") as f:
@@ -107,16 +111,29 @@ def test_float_parity_seed_sweep(name):
     print(rep)
     assert s["seeds"] == SW.seeds_of(name) and s["joints"] > 300
     assert s["centres_exact"], "proposal centres / valid flags differ from the reference"
-    if name in ("panoptic_b8", "panoptic128_b1", "panoptic_b32"):
+    if name != "campus_b2":
+        # R1, literal: since round 6 for Shelf too (its single exception of rounds 3-5 - seed 6, frame 0, slot 4, joint 4:
+        # 1.008e-3 mm in a proposal whose own reference floor is 1.46e-3 mm - reads 9.86e-4 mm since k_conv7 re-ordered
+        # P2PNet's front conv; the drift gate below pins that figure)
         assert s["violations_where_floor_le_4e-4"] == 0, s                       # R1
     assert s["violations_in_proposals_with_floor_le_4e-4"] == 0, s               # R1p
     if name != "campus_b2":
         assert s["violations_r1q"] == 0 and s["joints_r1q"] > 300, s             # R1q (Shelf: 910 joints in round 3)
     assert name == "campus_b2" or s["joints_of_proposals_with_floor_le_4e-4"] > 300
     assert s["worst_err_over_proposal_floor"] <= 3.0, s                          # R2
+    # The factors are MEASURED, not chosen (round 6): tests/golden/reorder_distribution.json holds the same ratios for the
+    # reference against ITSELF with another conv summation order (oneDNN on 8 threads vs ATen's native convs on one thread,
+    # make_reorder_distribution.py).  The build may be as far from the reference as the reference is from itself, with a
+    # margin of a quarter: worst proposal ratio <= 1.25 x the reference's own worst, and at least as many proposals within
+    # 2 x their floor as the reference manages, less 2 %.
+    mf = SW.measured_factors(name)
+    assert s["worst_err_over_proposal_floor"] <= max(1.25 * mf["joint_ratio_max"], 1.0), (s, mf)   # R2 with the measured factor
     if name == "campus_b2":                                                      # FLOOR_RULE over the whole sweep
-        assert s["proposals"] >= 90 and s["proposals_within_2x_own_floor"] >= 0.95 * s["proposals"], s
-        assert s["worst_proposal_err_over_own_floor"] <= 3.0, s
+        assert s["proposals"] >= 90 and s["proposals_within_2x_own_floor"] >= (mf["frac_within_2x"] - 0.02) * s["proposals"], (s, mf)
+        assert s["worst_proposal_err_over_own_floor"] <= 1.25 * mf["proposal_ratio_max"], (s, mf)
+    bad = drift_check("sweeps", name, s)
+    assert not bad, "float parity drifted past the pinned baseline (re-pin with tools/update_parity_baseline.py in the " \
+                    "same commit if intended): " + "; ".join(bad)
 
 
 def test_fused_projection_equals_materialised_full_size():

@@ -105,3 +105,25 @@ def test_no_readfirstlane_feeds_an_asm_buffer_access(rows):
     VALU-writes-SGPR -> VMEM hazard (5 wait states) would be violated silently: the gate counts such pairs in the ISA."""
     bad = [(r["demangled"].split("(")[0], r["readfirstlane_to_buffer_hazards"]) for r in rows if r["readfirstlane_to_buffer_hazards"]]
     assert not bad, bad
+
+
+def test_backbone_kernels_are_gated_too(rows):
+    """Round 6: the bf16 backbone's code objects under the same gate - no spills anywhere (covered
+    by test_no_shipped_kernel_spills: no exception entry names a k_bb_ kernel), and the fused kernels keep the shape their
+    occupancy plan relies on: k_bb_stem_pool <= 102 registers (two 9-wave workgroups per CU: five waves on a SIMD) with its 28
+    MFMAs per conv row unrolled; k_bb_bottleneck64 inside the 256 registers of two waves per SIMD with the 36 W2 operands
+    (144 registers) resident, i.e. no scratch."""
+    bb = [r for r in rows if "fvp::k_bb_" in r["demangled"]]
+    names = " ".join(r["demangled"] for r in bb)
+    for k in ("k_bb_stem_pool", "k_bb_bottleneck64<64, true>", "k_bb_bottleneck64<256, false>", "k_bb_conv_dma<256, 64, 2, false>",
+              "k_bb_conv_dma<256, 64, 2, true>", "k_bb_conv<64>", "k_bb_conv<128>"):
+        assert k in names, k
+    assert not any(k.startswith("k_bb") for k in ALTERNATE_FORMS)
+    for r in bb:
+        assert r["sgpr_spill"] == 0 and r["vgpr_spill"] == 0 and r["scratch"] == 0, r
+        if "k_bb_stem_pool" in r["demangled"]:
+            assert r["vgpr"] + r["agpr"] <= 102 and r["mfma"] == 28, r
+        if "k_bb_bottleneck64" in r["demangled"]:
+            assert 144 < r["vgpr"] + r["agpr"] <= 256, r
+            # conv1: 8 MFMAs per 64-channel block, two loop bodies when there is more than one block; conv2: 72; conv3 (+ downsample): 4 (+ 4)
+            assert r["mfma"] >= 72 + 8 + 4, r
