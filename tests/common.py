@@ -84,6 +84,8 @@ def parity_baseline():
 def drift_check(kind, name, rep):
     """kind = 'fixtures' (rep of check_outputs) or 'sweeps' (summary of seed_sweep.replay).  Returns the findings; the
     callers assert that the list is empty."""
+    if os.environ.get("FVP_TEST_DIAG_LIB") == "1":
+        return []          # tools/gpu_switch_matrix.sh: alternative kernels (other summation orders) on purpose; the bars above still apply
     base = parity_baseline()[kind].get(name)
     if base is None:
         return [f"{name}: no entry in tests/golden/parity_baseline.json (run tools/update_parity_baseline.py)"]
