@@ -661,10 +661,11 @@ def main():
                 pipe_legs = {"b1_eager": secondary_leg(args.config, 1, args.streams, 100, 8, dev, serial=False),
                              "b1_graph_slots": graph_slots_leg(args.config, 1, args.streams, 100, dev),
                              f"b{B}_graph_slots": graph_slots_leg(args.config, B, args.streams, 40, dev)}
-                leg = secondary_leg("panoptic", 8, 2, 10, 2, dev, backbone=True)
+                leg = secondary_leg("panoptic", 8, 3, 12, 3, dev, backbone=True)
                 gf = BACKBONE_GFLOP_PER_VIEW * 5
                 e2e = dict(leg, what="BASELINE configs[4] shape on one GPU: 5 x [3,512,960] images per frame -> bf16 "
-                                     "Pose-ResNet-50 (v_mfma_f32_32x32x16_bf16) -> voxel path, B = 8, 2 batches in flight",
+                                     "Pose-ResNet-50 (v_mfma_f32_32x32x16_bf16; stem + max-pool and layer1's bottlenecks as fused kernels) -> voxel path, "
+                                     "B = 8, 3 batches in flight",
                            backbone_gflop_per_frame=gf)
                 # backbone alone (serial, HIP-event timed by the library) for its own roofline fraction
                 e2e.update(backbone_alone(dev))

@@ -4,7 +4,7 @@
 # 1. GPU parity suite (parity report)      2. bench: default line + batch / pipeline-depth sweep + end-to-end
 # 3. rocprofv3 --kernel-trace --stats of the serial B=8 step and of the backbone
 # 4. PMC passes (SQ, GRBM, TCC, FETCH_SIZE, WRITE_SIZE: one group per pass) + summaries
-tag="${1:-r03}"; commit="${2:-?}"
+tag="${1:-r06}"; commit="${2:-?}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out"; dst="$out/profiles_${tag}"
 mkdir -p "$dst"
@@ -47,3 +47,7 @@ bash tools/gpu_pmc.sh "$tag" 2>&1 | tail -8
 python tools/pmc_summary.py "$tag" "$dst/${tag}_pmc_traffic.json" "$commit" > "$dst/${tag}_pmc_summary.txt" 2>&1
 head -30 "$dst/${tag}_pmc_summary.txt" | cut -c1-200
 cat "$dst/${tag}_pmc_traffic.json"
+echo "== backbone fused kernels: phase ablations + PMC"
+bash tools/gpu_r06_bbpmc.sh "$tag" > "$dst/${tag}_backbone_fused_ablate_pmc.txt" 2>&1; tail -5 "$dst/${tag}_backbone_fused_ablate_pmc.txt" | cut -c1-200
+echo "== SQ passes (conv kernels)"
+bash tools/gpu_pmc_sq.sh "$tag" > "$dst/${tag}_pmc_sq_conv.txt" 2>&1; tail -4 "$dst/${tag}_pmc_sq_conv.txt" | cut -c1-200
