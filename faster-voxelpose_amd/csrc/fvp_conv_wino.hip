@@ -21,6 +21,10 @@
 //   Xs[CC][TN][TH+2][4 + W]   zero-margin dense rows (halo reads need no masking)
 //   Ws[CC][32*WC][16]         quad q of row `co` stored at quad q ^ ((co>>2)&3): the four
 //                             ds_read_b128 of a lane (xi = 0..3) are bank-conflict free unpadded
+// (That is the A operand.  The B operand's patch reads are NOT conflict-free: a patch starts at image x - 1 = an odd column
+// of the row slot, the 16 tile lanes step by two floats and the four channel groups by a multiple of four, so an instruction's
+// 64 lanes share the 32 odd banks - SQ_LDS_BANK_CONFLICT reads 2.9 cycles per LDS instruction in the 64-128-channel variants;
+// DESIGN.md section 8 says why the layout stays.)
 //
 // Round 5 rewrite of the control structure (same arithmetic, same bits).  The round-4 kernel spilled 20-64 SGPRs in
 // every variant (243 v_readlane in the 64-cout form), carried ~470 scalar compares / branches and 159 s_waitcnt per chunk

@@ -302,7 +302,12 @@ int fvp_bb_pack(const float* weight, const float* bias, const float* bn_gamma, c
                 const float* bn_mean, const float* bn_var, float eps, const FvpBbOp* op, uint16_t* wblob,
                 float* eblob, fvp_stream_t s);
 /* run the op list on N images; bufs[i] = NHWC bf16 activation buffer i.  The first 64 floats of eblob must be
- * zero (e_off >= 64): the LDS-DMA of the large-tile kernel reads them for padding. */
+ * zero (e_off >= 64): the LDS-DMA of the large-tile kernel reads them for padding.
+ * Op patterns the list holds in sequence run as ONE kernel each, with the bits of the op-by-op launches (ABI 8):
+ * stem conv (+ bn, ReLU) followed by its max-pool (resnet.py:103-106, :185-188), and a 64-plane bottleneck
+ * [1x1 downsample,] 1x1 -> 3x3 -> 1x1 + residual (resnet.py:57-95) on one map - provided nothing else in the list
+ * reads the intermediate buffers, which then stay unwritten.  The 1x1 heatmap layer behind the last transposed
+ * conv is applied in that conv's epilogue. */
 int fvp_bb_run(const FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblob, void* const* bufs, int nbufs,
                int N, float* heat_cl, int heat_jp, float* heat_nchw, fvp_stream_t s);
 /* optional, once per (op list, N): times every conv op with each tile configuration of the large-tile kernel and
