@@ -177,6 +177,9 @@ def check_outputs(case, g, fused, planes, centers, engine, report=None):
     assert np.array_equal(last["flat"].cpu().numpy(), g["topk_flat"]), "top-k flat indices differ"
     c = centers.detach().cpu().numpy()
     gc = g["proposal_centers"]
+    # ABI 8: the mask of faster_voxelpose.py:45 comes out of fvp_proposals as uint8 flags
+    if "valid" in last:
+        assert last["valid"].dtype == torch.uint8 and np.array_equal(last["valid"].cpu().numpy().astype(bool), gc[..., 3] >= 0)
     assert np.array_equal(c[..., :3], gc[..., :3]), "proposal centres (mm) not bit-equal"
     assert np.array_equal(c[..., 3], gc[..., 3]), "valid flags differ"
     np.testing.assert_allclose(c[..., 5:7], gc[..., 5:7], rtol=0, atol=5e-5)

@@ -111,11 +111,20 @@ def test_float_parity_seed_sweep(name):
     print(rep)
     assert s["seeds"] == SW.seeds_of(name) and s["joints"] > 300
     assert s["centres_exact"], "proposal centres / valid flags differ from the reference"
-    if name != "campus_b2":
-        # R1, literal: since round 6 for Shelf too (its single exception of rounds 3-5 - seed 6, frame 0, slot 4, joint 4:
-        # 1.008e-3 mm in a proposal whose own reference floor is 1.46e-3 mm - reads 9.86e-4 mm since k_conv7 re-ordered
-        # P2PNet's front conv; the drift gate below pins that figure)
+    if name in ("panoptic_b8", "panoptic128_b1", "panoptic_b32"):
         assert s["violations_where_floor_le_4e-4"] == 0, s                       # R1
+    if name == "shelf_b2":
+        # R1, literal, asserted for Shelf with ONE named exception instead of "reported" (VERDICT round 5, item 4): seed 6,
+        # frame 0, slot 4, joint 4 - a joint with floor 3.9e-4 mm in a proposal whose own reference floor is 1.46e-3 mm.  It
+        # read 1.008e-3 mm through the pixel-pair 7x7 form (rounds 3-5, and today under FVP_CONV_NO_K7 in the switch
+        # matrix) and reads 9.86e-4 mm through k_conv7: the default build has no violation at all (pinned by the drift gate).
+        det = np.load(os.path.join(os.path.dirname(REPORT), f"sweep_detail_{name}.npy"))
+        viol = det[(det[:, 5] <= SW.FLOOR_OK) & (det[:, 4] > det[:, 7])]        # columns: seed, frame, slot, joint, err, floor, pfloor, bar
+        named = {(6, 0, 4, 4)}
+        got = {tuple(int(v) for v in r[:4]) for r in viol}
+        assert got <= named, (got, viol[:, 4:7])
+        for r in viol:
+            assert r[6] >= 1.4e-3 and r[4] <= 1.05e-3, r                         # its proposal's own floor; barely over the bar
     assert s["violations_in_proposals_with_floor_le_4e-4"] == 0, s               # R1p
     if name != "campus_b2":
         assert s["violations_r1q"] == 0 and s["joints_r1q"] > 300, s             # R1q (Shelf: 910 joints in round 3)
@@ -127,6 +136,10 @@ def test_float_parity_seed_sweep(name):
     # margin of a quarter: worst proposal ratio <= 1.25 x the reference's own worst, and at least as many proposals within
     # 2 x their floor as the reference manages, less 2 %.
     mf = SW.measured_factors(name)
+    if os.environ.get("FVP_TEST_DIAG_LIB") == "1":
+        # switch-matrix rows run ALTERNATIVE kernels (other summation orders, e.g. the pixel-pair 7x7 form: Campus worst 2.77):
+        # they keep the pre-round-6 constants - the measured bars describe the shipped kernel selection
+        mf = {"joint_ratio_max": 3.0 / 1.25, "proposal_ratio_max": 3.0 / 1.25, "frac_within_2x": 0.97}
     assert s["worst_err_over_proposal_floor"] <= max(1.25 * mf["joint_ratio_max"], 1.0), (s, mf)   # R2 with the measured factor
     if name == "campus_b2":                                                      # FLOOR_RULE over the whole sweep
         assert s["proposals"] >= 90 and s["proposals_within_2x_own_floor"] >= (mf["frac_within_2x"] - 0.02) * s["proposals"], (s, mf)
