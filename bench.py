@@ -571,6 +571,9 @@ def main():
         if not args.no_prof:
             names = {capi.K_PROJECT_WHOLE: "project_whole", capi.K_PROJECT_TRIPLANE: "project_triplane",
                      capi.K_CONV: "conv_other", capi.K_CONV_WINO: "conv_winograd_3x3",
+                     # Winograd launches with fewer work units than workgroup slots (CenterNet's 80- / 40-wide levels since
+                     # round 6): launch-latency-bound, kept out of the dominant kernel's roofline
+                     capi.K_CONV_WINO_SMALL: "conv_winograd_3x3_sub_chip_launches",
                      capi.K_SOFTARGMAX: "softargmax_weightnet", capi.K_OTHER: "other"}
             for cls, nm in names.items():
                 ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
@@ -628,8 +631,10 @@ def main():
             roof["traffic"], roof["traffic_source"] = load_pmc_traffic(top, B, args.config)
             wino["tflops_algorithmic"] = tf(wino)
             conv["tflops"] = tf(conv)
-            allconv = {"ms_total": wino["ms_total"] + conv["ms_total"], "launches": wino["launches"] + conv["launches"],
-                       "flops": wino["flops"] + conv["flops"]}
+            wsm = kern["conv_winograd_3x3_sub_chip_launches"]
+            allconv = {"ms_total": wino["ms_total"] + conv["ms_total"] + wsm["ms_total"],
+                       "launches": wino["launches"] + conv["launches"] + wsm["launches"],
+                       "flops": wino["flops"] + conv["flops"] + wsm["flops"]}
             allconv["tflops_algorithmic"] = tf(allconv)
             kern["conv_all"] = allconv
             kern["per_step_ms"] = {nm: kern[nm]["ms_total"] / prof_steps for nm in names.values()}

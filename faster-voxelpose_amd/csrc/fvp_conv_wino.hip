@@ -640,6 +640,7 @@ k_pack_wino(const float* __restrict__ w, int cin, int cout, int cinp, int coutp,
 // host side
 static const size_t kWinoLdsBudget = env_size("FVP_WINO_LDS_KB", 152) * 1024;
 static const int kWinoGeneric = int(env_size("FVP_WINO_GENERIC", 0));
+constexpr int kWinoMaskedMinW = 40;     // narrowest non-power-of-two row that takes masked Winograd tiles (netspec.WINO_MASKED_MIN_W)
 static const int kWinoWC1 = int(env_size("FVP_WINO_WC1", 0));        // diagnostics: 32-cout blocks for every layer
 // 4-wave workgroups (32 couts x 64 tiles, <= 78 KB of LDS, two per CU) instead of one 8-wave workgroup per CU:
 // half-size work units.  Slower per FLOP when the launch has plenty of units (more LDS-DMA traffic per MFMA), but
@@ -670,12 +671,17 @@ int persistent_workgroups() {
 // planes), so a frame's result does not depend on the batch it is computed in.
 static bool wino_tiling(int h, int w, int cinp, int coutp, int* WC, int* WT, int* TN, int* TR, bool half = false) {
   if (h < 2 || (h & 1) || w < 8 || (w & 3) || (coutp != 32 && coutp % 64 != 0) || cinp % 4 != 0) return false;
-  // Maps whose rows do not divide the workgroup tile (CenterNet's 80x80 / 40x40 / 20x20 levels) are supported
-  // (masked tiles) but stay on the direct kernel by default: with a handful of planes the Winograd kernel is
-  // launch-latency bound just the same (measured 582 vs 564 us for CenterNet at B = 8), and the direct form is the
-  // exact fp32 fma chain, which keeps the detection map - the input of the bit-exact top-k - closest to the
-  // reference.  FVP_WINO_GENERIC=1 enables them (a SHAPE rule either way, never the batch).
-  if ((w & (w - 1)) && !kWinoGeneric) return false;
+  // Maps whose rows do not divide the workgroup tile (CenterNet's 80x80 / 40x40 / 20x20 levels) run with masked tiles.
+  // Until round 5 they stayed on the direct kernel (582 vs 564 us for CenterNet at B = 8 in round 3: launch-latency bound
+  // either way).  Since round 5's rewrite of this kernel the masked form wins on the 80- and 40-wide levels at every batch
+  // (round 6, same box: 3x3 layers 23 -> 14.7 / 19.5 -> 13.8 us at B = 8, 11.5 -> 8 / 18.5 -> 13.2 us at B = 1; CenterNet
+  // 496 -> ~420 us per pass at B = 8, 379 -> ~330 us at B = 1), while the 20-wide level is faster on the split-K direct form
+  // at B = 1 (17 vs 22 us; one or two workgroups of tiles).  So: rows of >= 40 columns take masked tiles, narrower ones the
+  // direct kernel - a SHAPE rule, never the batch.  The detection map moves by fp32 rounding only: the GPU suite (top-k
+  // indices, proposal centres and valid flags exact on every golden and sweep) is green with it and the joints do not change
+  // by a bit (the joint stage reads nothing of CenterNet's float values).  FVP_WINO_GENERIC=1 (diagnostics build) takes
+  // every width.
+  if ((w & (w - 1)) && w < kWinoMaskedMinW && !kWinoGeneric) return false;
   *WC = (coutp == 32 || kWinoWC1 || half) ? 1 : 2;
   *WT = (half ? 4 : 8) / *WC;
   // a unit = TN planes x TR tile rows x (w/2) tiles <= the workgroup's 16*WT tiles; tiles beyond that product
@@ -835,7 +841,8 @@ int wino_plan_and_launch(const FvpConvOp& op, ConvArgs a, const float* params, i
   static const int kBalanced = int(env_size("FVP_WINO_BALANCED", 0));
   const int slots = persistent_workgroups() * (WC * WT == 4 ? 2 : 1);
   dim3 grid(kBalanced ? ceil_div(a.nunits, ceil_div(a.nunits, slots)) : std::min(a.nunits, slots), 1, 1);
-  ProfScope ps(FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1, prof_level() >= 2);
+  ProfScope ps(a.nunits < slots ? FVP_K_CONV_WINO_SMALL : FVP_K_CONV_WINO, s, 2.0 * op.cin * op.cout * 9.0 * op.h * op.w * planes, 1,
+               prof_level() >= 2);
 #if FVP_DIAG
   if (w16) {
     if (CC != 8 || ni > 2) return FVP_ELIMIT;        // (shapes outside the 16-wave instances)

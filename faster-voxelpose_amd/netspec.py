@@ -59,8 +59,11 @@ class ParamTree(nn.Module):
         raise RuntimeError("ParamTree holds parameters only")
 
 
-# Set by tests that load the diagnostics build with FVP_WINO_GENERIC=1 (masked Winograd tiles for rows that do not
-# divide the workgroup tile); the shipped library never takes that path, and nothing here reads the environment.
+# Rows that do not divide the Winograd workgroup tile (CenterNet's 80 / 40 / 20-wide levels) run with masked tiles when
+# they are at least WINO_MASKED_MIN_W columns wide (round 6; kWinoMaskedMinW in csrc/fvp_conv_wino.hip), narrower ones on the
+# direct kernel.  WINO_GENERIC: set by tests that load the diagnostics build with FVP_WINO_GENERIC=1 (every width);
+# nothing here reads the environment.
+WINO_MASKED_MIN_W = 40
 WINO_GENERIC = False
 
 
@@ -73,8 +76,8 @@ def winograd_shape(kh, kw, h, w, cinp, coutp, cin=None, cout=None):
         return False
     if cout is not None and (cout % 32 or cout != coutp):   # whole 32-cout blocks, no padded couts (the epilogue has no per-cout predicate)
         return False
-    if w & (w - 1) and not WINO_GENERIC:
-        return False                             # rows that do not divide the workgroup tile: direct kernel by default
+    if w & (w - 1) and w < WINO_MASKED_MIN_W and not WINO_GENERIC:
+        return False                             # narrow rows that do not divide the workgroup tile: direct kernel
     return w // 2 <= (128 if coutp == 32 else 64)   # a tile row fits the workgroup's 16 * WT tiles
 
 

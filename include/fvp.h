@@ -321,11 +321,14 @@ int fvp_bb_tune(FvpBbOp* ops, int nops, const uint16_t* wblob, const float* eblo
  * on -- per launch for the projection / soft-argmax / small kernels, one pair per
  * fvp_conv_stack_run for the conv class (launches = convs in the stack), so that a ~100-launch
  * step is not perturbed.  fvp_prof_enable(2): one pair per conv LAUNCH instead, the Winograd 3x3
- * launches (the dominant kernel) in their own class FVP_K_CONV_WINO, all others in FVP_K_CONV.
+ * launches (the dominant kernel) in their own class FVP_K_CONV_WINO, all others in FVP_K_CONV.  Winograd launches with
+ * fewer work units than the chip has workgroup slots (CenterNet's levels since round 6, everything at B = 1) are
+ * launch-latency-bound, not matrix-core-bound: they go to FVP_K_CONV_WINO_SMALL so that the roofline of the
+ * chip-filling launches stays what it describes.
  * fvp_prof_read synchronises the events and returns accumulated milliseconds, launch count and
  * algorithmic FLOPs since the last reset. */
 enum { FVP_K_PROJECT_WHOLE = 0, FVP_K_PROJECT_TRIPLANE = 1, FVP_K_CONV = 2, FVP_K_SOFTARGMAX = 3,
-       FVP_K_OTHER = 4, FVP_K_CONV_WINO = 5, FVP_K_BACKBONE = 6, FVP_K_COUNT = 7 };
+       FVP_K_OTHER = 4, FVP_K_CONV_WINO = 5, FVP_K_BACKBONE = 6, FVP_K_CONV_WINO_SMALL = 7, FVP_K_COUNT = 8 };
 int fvp_prof_enable(int on);
 int fvp_prof_read(int cls, double* ms, int64_t* launches, double* flops);
 int fvp_prof_reset(void);

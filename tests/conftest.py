@@ -61,3 +61,6 @@ def pytest_sessionstart(session):
     if os.environ.get("FVP_TEST_DIAG_LIB") == "1":
         from faster_voxelpose_amd import _capi as capi
         capi.LIB_PATH = _diag_path()
+        if os.environ.get("FVP_WINO_GENERIC") == "1":    # host mirror of the library's switch (weight-blob layout)
+            from faster_voxelpose_amd import netspec
+            netspec.WINO_GENERIC = True

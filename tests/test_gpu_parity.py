@@ -241,7 +241,8 @@ def test_nms_topk_exact_vs_oracle():
                                                  (128, 64, (40, 40), 2)])
 def test_split_k_direct_conv_on_small_maps(cin, cmid, hw, planes):
     """CenterNet's 3x3 layers on the 20x20 level (maps of 256 .. 576 pixels, >= 64 channels) run the split-K form of the
-    direct kernel (four waves share a pixel block, fixed-order reduction); 40x40 stays on the plain form.  Against a
+    direct kernel (four waves share a pixel block, fixed-order reduction); the 40x40 case runs masked Winograd tiles since
+    round 6 (rows of >= 40 columns: netspec.WINO_MASKED_MIN_W).  Against a
     float64 torch evaluation, and bit-identical for a plane whatever the number of planes in the launch (the form is
     chosen from the layer shape, never from the batch)."""
     from faster_voxelpose_amd import _capi as capi

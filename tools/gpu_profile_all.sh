@@ -38,6 +38,7 @@ echo "== rocprofv3 kernel trace"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}" -o trace -- python "$root/bench.py" --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-prof --no-mpjpe --no-extra > "$out/rocprof_${tag}.log" 2>&1; echo "rocprof rc=$?"
 find "$out/prof_${tag}" -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} "$dst/${tag}_kernel_stats_b8.csv"
+find "$out/prof_${tag}" -name "*kernel_trace.csv" | head -1 | xargs -r -I{} python "$root/tools/wino_by_grid.py" {} > "$dst/${tag}_kernel_stats_b8_wino_by_launch_size.txt" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_bb" -o trace -- python "$root/tools/bench_backbone.py" --images 40 --iters 3 > "$out/rocprof_${tag}_bb.log" 2>&1
 find "$out/prof_${tag}_bb" -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} "$dst/${tag}_kernel_stats_backbone.csv"
 head -12 "$dst/${tag}_kernel_stats_b8.csv" | cut -c1-160
