@@ -146,7 +146,8 @@ int fvp_project_individual_triplane(const float* heat_cl, const float* cams, con
  * [planes][C][H][W]; 1-D nets use H = 1).  The same interpreter runs CenterNet
  * (cnns_2d.py:147-178), C2CNet (cnns_1d.py:112-132) and P2PNet (cnns_2d.py:115-135).
  * Convs run on the fp32 matrix cores, the kernel chosen from the layer SHAPE alone (never the batch): 3x3 layers on
- * power-of-two maps as Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (k_conv_wino), P2PNet's 7x7 front conv on
+ * power-of-two maps and on rows of >= 40 columns (masked tiles: CenterNet's 80- / 40-wide levels, ABI 8) as Winograd
+ * F(2x2,3x3) on v_mfma_f32_16x16x4_f32 (k_conv_wino), P2PNet's 7x7 front conv on
  * 16x16x4 tiles (k_conv7), 1x1 / transposed convs register-direct (k_conv_reg), everything else as implicit GEMMs on
  * v_mfma_f32_32x32x2_f32 (k_conv_dma); the whole 1-D stack in one kernel (fvp_conv_stack_run_fused_1d).
  * BatchNorm (eval) is applied in the epilogue as  y = (acc + bias) * bn_scale + bn_shift  (no weight folding, to stay
