@@ -200,27 +200,47 @@ def test_backbone_emulated_matches_bf16_oracle(emu_lib):
     assert torch.equal(cl[..., :J], y.reshape(1, J, -1).permute(0, 2, 1)) and not cl[..., J:].any()
 
 
-@pytest.mark.parametrize("hw", [(32, 32), (64, 96)])
+@pytest.mark.parametrize("hw", [(32, 32), (64, 160)])
 def test_backbone_fused_stem_pool_equals_the_two_launches(emu_lib, monkeypatch, hw):
-    """k_bb_stem_pool (conv1 + bn1 + ReLU + max-pool in one kernel, round 6) against the stem conv and the pooling as two
-    launches (FVP_BB_NO_FUSE_STEM=1, diagnostics build): the same MFMA chain per conv pixel, so the heatmaps must be
-    bit-equal - on an image smaller than one tile and on one with ragged tiles in both directions."""
+    """k_bb_stem_pool (conv1 + bn1 + ReLU + max-pool in one kernel, round 6) and k_bb_bottleneck64 (a layer1 bottleneck in one
+    kernel, with and without the downsample branch) against the layer-by-layer launches (FVP_BB_NO_FUSE_STEM / _BLOCK,
+    diagnostics build): the same MFMA chains and roundings per output, so the stage's output tensor must be bit-equal - on an
+    image smaller than one tile and on one with ragged tiles and two tile columns.  Only the stem and layer1 are run (the op
+    list up to the last layer1 block through fvp_bb_run): the rest of the network is covered by the test above."""
+    import ctypes as C
+    from faster_voxelpose_amd import _capi as capi
     from faster_voxelpose_amd.core import config as CFG
     from faster_voxelpose_amd.models import resnet as RN
     cfg = CFG.default_config()
     cfg.DEVICE = "cpu"
     m = RN.PoseResNet(cfg, _lib=emu_lib)
     m.load_state_dict(S.fill_backbone_state_dict(m.state_dict(), seed=5))
-    x = torch.from_numpy(np.random.default_rng(1).random((2, 3) + hw, dtype=np.float32))
-    fused = m(x)
+    N, (H, W) = 2, hw
+    x = torch.from_numpy(np.random.default_rng(1).random((N, 3, H, W), dtype=np.float32))
+    plan = m._plan(H, W)
+    m.ensure_packed(plan)
+    nops = 1 + max(i for i, o in enumerate(m._convs) if str(o.get("key", "")).startswith("layer1."))
+    last = plan["ops"][nops - 1].dst
+
+    def run():
+        bufs = []
+        for name in plan["names"]:
+            c, h, w = plan["shapes"][name]
+            bufs.append(torch.zeros((N, h, w // 2, c) if name == "x" else (N, h, w, c), dtype=torch.bfloat16))
+        capi.check(emu_lib, emu_lib.fvp_bb_input(C.c_void_p(x.data_ptr()), C.c_void_p(bufs[0].data_ptr()), N, 3, H, W, None), "input")
+        arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+        capi.check(emu_lib, emu_lib.fvp_bb_run(plan["ops"], nops, C.c_void_p(m._wblob.data_ptr()), C.c_void_p(m._eblob.data_ptr()),
+                                               arr, len(bufs), N, None, 0, None, None), "fvp_bb_run")
+        return bufs[last].clone()
+
+    fused = run()
     monkeypatch.setenv("FVP_BB_NO_FUSE_STEM", "1")
-    two = m(x)
-    assert float(fused.abs().max()) > 0 and torch.equal(fused, two)
-    # ... and layer1's bottlenecks (k_bb_bottleneck64, with and without the downsample branch) against the layer-by-layer
-    # launches: the same chains and roundings, bit-equal
+    no_stem = run()
     monkeypatch.setenv("FVP_BB_NO_FUSE_BLOCK", "1")
-    plain = m(x)
-    assert torch.equal(fused, plain), float((fused - plain).abs().max())
+    plain = run()
+    assert float(fused.float().abs().max()) > 0
+    assert torch.equal(fused.view(torch.int16), no_stem.view(torch.int16)), "stem"
+    assert torch.equal(fused.view(torch.int16), plain.view(torch.int16)), "bottleneck"
 
 
 def test_cached_fine_grid_gives_identical_planes(emu_lib):
