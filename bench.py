@@ -328,6 +328,7 @@ class Workload:
         return self.gatherer.gather(fused, ev)
 
     def sync(self):
+        self.gatherer.synchronize()              # host-issued gathers still waiting for their batch are enqueued here
         self.torch.cuda.synchronize()
 
 
@@ -367,14 +368,19 @@ def timed_region(wl, steps, warmup, dist_on, dev):
         if dist_on:
             dist.barrier()
         wl.sync()
+        pipe = getattr(wl, "pipe", None)
+        w0 = pipe.wait_s if pipe is not None else 0.0
         t0 = time.perf_counter()
         for i in range(steps):
             out = wl.step(i)
         t_sub = time.perf_counter()
+        waited = (pipe.wait_s - w0) if pipe is not None else 0.0
         wl.sync()                                # every stream of the device: compute pipeline and gathers
-        # host time spent enqueueing the K steps, and how long the GPU still ran afterwards (GPU-bound when the drain is
-        # long: the host is ahead of the device)
-        HOST_TIMES.update(submit_ms_per_step=1e3 * (t_sub - t0) / max(1, steps), drain_ms=1e3 * (time.perf_counter() - t_sub))
+        # host time spent ENQUEUEING the K steps (the pipeline's back-pressure wait - the host blocked until the slot's
+        # previous batch had finished - is reported apart), and how long the GPU still ran after the last enqueue
+        HOST_TIMES.update(submit_ms_per_step=1e3 * (t_sub - t0 - waited) / max(1, steps),
+                          backpressure_wait_ms_per_step=1e3 * waited / max(1, steps),
+                          drain_ms=1e3 * (time.perf_counter() - t_sub))
         if os.environ.get("FVP_BENCH_DEBUG"):
             print(f"[debug] submit {1e3 * (t_sub - t0):.2f} ms, drain {1e3 * (time.perf_counter() - t_sub):.2f} ms",
                   file=sys.stderr)
@@ -516,7 +522,8 @@ def main():
     assert hi - lo == B
     # the gather of batch t runs on its own stream behind batch t's completion event, so it never fences
     # the compute pipeline (core/distributed.py)
-    gatherer = D.ResultGatherer(world, device=dev, always=force_dist)
+    # FVP_GATHER_ISSUE=stream (diagnostics): the pre-round-6 GPU-side event wait instead of the host-issued gather
+    gatherer = D.ResultGatherer(world, device=dev, always=force_dist, issue=os.environ.get("FVP_GATHER_ISSUE", "host"))
     lib = capi = None
     if STUB:
         wl = StubWorkload(B, rank, gatherer)
@@ -537,8 +544,11 @@ def main():
         dist.barrier()
     dt, out = timed_region(wl, args.steps, args.warmup, dist_on, dev)
     headline_host = {"submit_ms_per_step": HOST_TIMES.get("submit_ms_per_step"), "drain_ms": HOST_TIMES.get("drain_ms"),
-                     "what": "host time to enqueue one step of the timed region (Python + ctypes launches), and how long the "
-                             "GPU still ran after the last enqueue (long drain = the GPU, not the host, is the limit)"}
+                     "backpressure_wait_ms_per_step": HOST_TIMES.get("backpressure_wait_ms_per_step"),
+                     "what": "host time to enqueue one step of the timed region (Python + ctypes launches); time the host was "
+                             "blocked by the pipeline's back-pressure (it may be at most `batches_in_flight` batches ahead of "
+                             "the GPU: a long wait = the GPU, not the host, is the limit); and how long the GPU still ran "
+                             "after the last enqueue"}
     assert out.shape[0] == B * world
     valid_people = float((out[..., 0, 3] >= 0).sum().item()) / out.shape[0]
 

@@ -101,10 +101,15 @@ class PipelinedForward:
     ``event.wait()`` (or after ``synchronize()``).  Results are identical to the plain forward:
     every kernel is deterministic and replicas share nothing but read-only inputs."""
 
-    def __init__(self, model, depth=2, streams=None):
+    def __init__(self, model, depth=2, streams=None, backpressure=True):
         """``streams``: optional list of >= depth ``torch.cuda.Stream`` to run on (a process that builds several pipelines
         should hand them the same streams: the HIP runtime maps streams onto a fixed number of hardware queues -
-        GPU_MAX_HW_QUEUES, default 4 - and streams that share a queue serialise)."""
+        GPU_MAX_HW_QUEUES, default 4 - and streams that share a queue serialise).
+        ``backpressure`` (round 6): before a slot is reused the HOST waits for the batch that ran in it last, so the host is
+        never more than ``depth`` batches ahead of the GPU - nothing changes for the GPU (it always has depth - 1 batches
+        queued: 3 235-3 239 frames/s with, 3 238-3 244 without), results can be consumed as they complete
+        (``ResultGatherer.poll``) and the outputs of unboundedly many queued batches do not pile up.  ``wait_s`` accumulates
+        the host time spent in that wait."""
         assert depth >= 1
         assert streams is None or len(streams) >= depth
         self.models = [model]
@@ -119,11 +124,19 @@ class PipelinedForward:
             self.models.append(m)
         self.depth = depth
         self._i = 0
+        self.backpressure = bool(backpressure)
+        self._last = [None] * depth                      # completion event of the batch that last ran in each slot
+        self.wait_s = 0.0
 
     def submit(self, **forward_kwargs):
         k = self._i % self.depth
         self._i += 1
         st = self.streams[k]
+        if self.backpressure and self._last[k] is not None:
+            import time
+            t0 = time.perf_counter()
+            self._last[k].synchronize()
+            self.wait_s += time.perf_counter() - t0
         st.wait_stream(torch.cuda.current_stream())      # inputs produced on the caller's stream
         # the inputs were allocated on the caller's stream but are read on `st`: tell the caching
         # allocator, or a caller that drops them right after submit() could see the block handed
@@ -135,6 +148,7 @@ class PipelinedForward:
             out = self.models[k](**forward_kwargs)
             ev = torch.cuda.Event()
             ev.record(st)
+        self._last[k] = ev
         return out, ev
 
     @staticmethod

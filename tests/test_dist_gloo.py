@@ -149,6 +149,74 @@ def test_forced_gather_at_world_size_one_runs_the_collective():
     assert ("comm", "wait_event", "done0") in log
 
 
+class _MockEvent:
+    """An event with torch.cuda.Event's host-side interface: complete after `after` calls of query(), or once synchronize()
+    has been called."""
+
+    def __init__(self, name, after, log):
+        self.name, self.left, self.log = name, after, log
+
+    def query(self):
+        self.left -= 1
+        return self.left < 0
+
+    def synchronize(self):
+        self.log.append(("host", "event_synchronize", self.name))
+        self.left = -1
+
+
+def _worker_host_issue(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from faster_voxelpose_amd.core import distributed as D
+    lo, hi = D.shard_frames(total, world, rank)
+    log = []
+    comm = _LogStream("comm", log)
+    gat = D.ResultGatherer(world, stream=comm, stream_ctx=_Ctx)            # issue="host" is the default
+    outs, issued_after = [], []
+    for step in range(4):
+        local = _fake_hot_path(torch.arange(lo, hi, dtype=torch.float32) + 100 * step)
+        # batch `step` finishes two polls after it was submitted (both ranks alike: the collectives must pair up)
+        outs.append(gat.gather(local, _MockEvent(f"done{step}", 2, log)))
+        issued_after.append(sum(1 for e in log if e == ("comm", "enter", None)))
+    pending_before_sync = len(gat._pending)
+    gat.synchronize()
+    dist.barrier()
+    if rank == 0:
+        q.put(([o.clone() for o in outs], log, issued_after, pending_before_sync))
+    dist.destroy_process_group()
+
+
+def test_host_issued_gather_has_no_gpu_side_wait_and_keeps_the_order():
+    """Round 6 default: the collective of a batch is enqueued by the HOST once the batch's event reports completion
+    (ResultGatherer.poll), so no stream ever carries a wait for it - a waiting packet in the communication stream's queue cost
+    the compute streams 7-9 % on the MI355X (core/distributed.py).  Gathers are issued in submission order, only for
+    finished batches; synchronize() host-waits for the rest and issues them; results equal the single-process ones."""
+    total, world = 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker_host_issue, args=(r, world, 29623, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs, log, issued_after, pending_before_sync = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for step, out in enumerate(outs):
+        want = torch.cat([_fake_hot_path(torch.arange(r * 4, r * 4 + 4, dtype=torch.float32) + 100 * step) for r in range(world)])
+        assert torch.equal(out, want)
+    assert not any(e[1] in ("wait_event", "wait_stream") for e in log), "host-issued gathers put no wait into any stream"
+    # a batch's collective is never enqueued by the gather() call that submitted it (its event is not complete yet), the
+    # backlog drains in order, and whatever is still pending at the end is completed by synchronize()
+    assert issued_after[0] == 0 and issued_after == sorted(issued_after) and issued_after[-1] < 4
+    assert pending_before_sync == 4 - issued_after[-1] >= 1
+    assert sum(1 for e in log if e == ("comm", "enter", None)) == 4
+    waited = [e[2] for e in log if e[1] == "event_synchronize"]
+    assert waited == [f"done{k}" for k in range(4 - pending_before_sync, 4)]
+    assert log[-1] == ("comm", "synchronize", None)
+
+
 def _worker_no_event(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
