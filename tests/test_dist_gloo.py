@@ -83,7 +83,7 @@ def _worker(rank, world, port, total, q):
     gat.synchronize()
     dist.barrier()
     if rank == 0:
-        q.put((outs, log))
+        q.put(([o.numpy() for o in outs], log))
     dist.destroy_process_group()
 
 
@@ -96,6 +96,7 @@ def test_sharded_gather_equals_single_process_and_never_fences_the_pipeline():
     for p in procs:
         p.start()
     outs, log = q.get()
+    outs = [torch.from_numpy(o) for o in outs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -131,7 +132,7 @@ def _worker_always(port, q):
     x = _fake_hot_path(torch.arange(0, 8, dtype=torch.float32))
     out = gat.gather(x, "done0")
     gat.synchronize()
-    q.put((out.clone(), out.data_ptr() != x.data_ptr(), log))
+    q.put((out.clone().numpy(), out.data_ptr() != x.data_ptr(), log))
     dist.destroy_process_group()
 
 
@@ -143,6 +144,7 @@ def test_forced_gather_at_world_size_one_runs_the_collective():
     p = ctx.Process(target=_worker_always, args=(29617, q))
     p.start()
     out, copied, log = q.get()
+    out = torch.from_numpy(out)
     p.join(60)
     assert p.exitcode == 0
     assert torch.equal(out, _fake_hot_path(torch.arange(0, 8, dtype=torch.float32))) and copied
@@ -184,7 +186,7 @@ def _worker_host_issue(rank, world, port, total, q):
     gat.synchronize()
     dist.barrier()
     if rank == 0:
-        q.put(([o.clone() for o in outs], log, issued_after, pending_before_sync))
+        q.put(([o.clone().numpy() for o in outs], log, issued_after, pending_before_sync))
     dist.destroy_process_group()
 
 
@@ -200,6 +202,7 @@ def test_host_issued_gather_has_no_gpu_side_wait_and_keeps_the_order():
     for p in procs:
         p.start()
     outs, log, issued_after, pending_before_sync = q.get()
+    outs = [torch.from_numpy(o) for o in outs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -228,7 +231,7 @@ def _worker_no_event(port, q):
     x = _fake_hot_path(torch.arange(0, 8, dtype=torch.float32))
     out = gat.gather(x)                       # no completion event (plain forward / hipGraph replay)
     gat.synchronize()
-    q.put((out.clone(), log))
+    q.put((out.clone().numpy(), log))
     dist.destroy_process_group()
 
 
@@ -241,6 +244,7 @@ def test_gather_without_event_is_ordered_behind_the_callers_stream():
     p = ctx.Process(target=_worker_no_event, args=(29619, q))
     p.start()
     out, log = q.get()
+    out = torch.from_numpy(out)
     p.join(60)
     assert p.exitcode == 0
     assert torch.equal(out, _fake_hot_path(torch.arange(0, 8, dtype=torch.float32)))
@@ -326,7 +330,7 @@ def _worker_real_path(rank, world, port, q):
             if rank == 0 else None
     dist.barrier()
     if rank == 0:
-        q.put((out, whole))
+        q.put((out.numpy(), whole.numpy()))
     dist.destroy_process_group()
 
 
@@ -340,7 +344,7 @@ def test_sharded_real_hot_path_equals_single_process_bit_for_bit():
     procs = [ctx.Process(target=_worker_real_path, args=(r, world, 29627, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, whole = q.get()
+    out, whole = (torch.from_numpy(a) for a in q.get())
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
