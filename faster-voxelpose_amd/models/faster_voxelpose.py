@@ -5,6 +5,8 @@
 cameras=None, resize_transform=None)`` returns
 ``(fused_poses [B,N,J,5], plane_poses [3,B,N,J,2], proposal_centers [B,N,7], input_heatmaps, None)``.
 """
+import time
+
 import torch
 import torch.nn as nn
 
@@ -133,7 +135,6 @@ class PipelinedForward:
         self._i += 1
         st = self.streams[k]
         if self.backpressure and self._last[k] is not None:
-            import time
             t0 = time.perf_counter()
             self._last[k].synchronize()
             self.wait_s += time.perf_counter() - t0
