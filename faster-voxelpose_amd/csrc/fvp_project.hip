@@ -901,7 +901,19 @@ extern "C" int fvp_project_individual_triplane(const float* heat_cl, const float
     if (fine_grid) CALLB(NVL_, true, false); else CALLB(NVL_, false, false);             \
   }
 #endif
-    if (nvl == 2) CALLB2(2) else CALLB2(1)
+    // JP = 20 (J = 17: Shelf / Campus): five channel quads - the fifth sampled for four voxels in one pass (Q5, round 6).
+    // FVP_TRI_NO_Q5=1 (diagnostics build) keeps the two-group form for comparison; same bits.
+    const bool q5 = nvl == 2 && g->JP == 20 && !zres && fvp::diag_env("FVP_TRI_NO_Q5") == nullptr;
+    if (q5) {
+      if (fine_grid)
+        hipLaunchKernelGGL((k_project_triplane_blk<2, true, false, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s),
+                           heat_cl, reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
+                           nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes, zsh);
+      else
+        hipLaunchKernelGGL((k_project_triplane_blk<2, false, false, true>), dim3(nbx2 * nby * nP), dim3(kBlkThreads), lds_b, as_stream(s),
+                           heat_cl, reinterpret_cast<const Cam*>(cams), frame_set, person_frame, person_valid, boxes, fx, fy, fz, C, nP,
+                           nbx2, nby, ppf, *g, fine_grid, F0, F1, F2, planes, zsh);
+    } else if (nvl == 2) CALLB2(2) else CALLB2(1)
 #undef CALLB2
 #undef CALLB
     return launch_status();

@@ -21,6 +21,7 @@
 // Two workgroups (1024 threads, <= 76 KB of LDS) share a CU: one samples while the other waits for
 // its DMA.  A rectangle that does not fit the tile falls back to global gathers for that view.
 #pragma once
+#include <type_traits>
 #include <climits>
 
 namespace fvp {
@@ -483,13 +484,21 @@ constexpr size_t kTriZresMaxLds = size_t(FVP_TRI_ZRES_MAX_KB) * 1024;   // z-res
 // z blocks and the x-y maxima stay in registers (the same lane owns a column in every z block): one zero fill, no barrier
 // inside the z loop, one merge into the global planes at the end - instead of zero fill + 3 barriers + merge per z block.
 // max is order-independent: same bits.
-template <int NVL, bool CACHED, bool ZRES>
+// Q5 (round 6; JP = 20: Shelf / Campus, J = 17): the channels are FIVE quads.  With two quad groups per lane (NVL = 2) the second
+// group holds one quad, so its sampling pass ran with three of a voxel's four lanes idle - 8 tap passes per four voxels where 5
+// would do.  Here the four broadcast passes sample channels 0-15 as for JP = 16, and ONE more pass samples channels 16-19 of all
+// four voxels at once: lane q takes voxel q's fifth quad with the tap descriptor it computed itself (no broadcast).  Same
+// arithmetic per sample, so the same bits; the accumulators of the fifth quad belong to (voxel 4k + q), which the plane-maxima
+// phase accounts for (its x-y maximum is reduced over the q lanes too).
+template <int NVL, bool CACHED, bool ZRES, bool Q5 = false>
 __global__ void __launch_bounds__(kBlkThreads, FVP_TRI_BLK_OCC)
 k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict__ cams, const int* __restrict__ frame_set,
                        const int* __restrict__ person_frame, const uint8_t* __restrict__ person_valid,
                        const int* __restrict__ boxes, const float* __restrict__ fx, const float* __restrict__ fy,
                        const float* __restrict__ fz, int C, int nP, int nbx, int nby, int ppf, FvpGeom g,
                        const float* __restrict__ fgrid, int F0, int F1, int F2, float* __restrict__ planes, int zsh) {
+  static_assert(!Q5 || (NVL == 2 && !ZRES), "the five-quad form replaces the two-group form of the per-z-block kernel");
+  constexpr int NVA = Q5 ? 1 : NVL;                  // quad groups sampled by the broadcast passes
   constexpr int BZ = NVL == 1 ? kBlkBZ : 16;
   constexpr int VPT = BZ / 4;
   constexpr int OWN = VPT / 4;
@@ -553,13 +562,18 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
   }
 
   for (int gz0 = s2; gz0 < e2; gz0 += BZ) {
-    float acc[VPT][NVL][4];
+    float acc[VPT][NVA][4];
 #pragma unroll
     for (int i = 0; i < VPT; ++i)
 #pragma unroll
-      for (int n = 0; n < NVL; ++n)
+      for (int n = 0; n < NVA; ++n)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[i][n][c] = 0.0f;
+    [[maybe_unused]] float accx[OWN][1][4];                              // Q5: channels 16-19 of voxel 4 k + q
+#pragma unroll
+    for (int kk = 0; kk < OWN; ++kk)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accx[kk][0][c] = 0.0f;
     float2 crd[OWN];
     auto load_coords = [&](int v) {
 #pragma unroll
@@ -605,11 +619,12 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
       if (mine[0].base != -12345) { acc[0][0][0] += mine[0].w[0] + mine[OWN - 1].w[3] + float(mine[0].base); continue; }
 #endif
       const float* gsrc = frame + size_t(v) * view_stride;
-      auto sample = [&](const TapL& tv, float (&a)[NVL][4]) {
+      auto sample = [&](const TapL& tv, auto& a, auto own) {
+        constexpr bool kOwn = decltype(own)::value;                      // Q5's extra pass: channels 16-19, every lane
 #pragma unroll
-        for (int n = 0; n < NVL; ++n) {
-          const int ch0 = 16 * n + 4 * q;
-          if (ch0 < JP) {
+        for (int n = 0; n < (kOwn ? 1 : NVA); ++n) {
+          const int ch0 = kOwn ? 16 : 16 * n + 4 * q;
+          if (kOwn || ch0 < JP) {
             const float* p0 = gsrc + tv.base + ch0;
             const float4 v0 = glb_ld4(p0), v1 = glb_ld4(p0 + tv.dx), v2 = glb_ld4(p0 + tv.dy), v3 = glb_ld4(p0 + tv.dy + tv.dx);
             const f32x2 w0 = f32x2{tv.w[0], tv.w[0]}, w1 = f32x2{tv.w[1], tv.w[1]}, w2 = f32x2{tv.w[2], tv.w[2]},
@@ -628,10 +643,11 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
       };
 #pragma unroll
       for (int k = 0; k < OWN; ++k) {
-        { const TapL tv = quad_bcast_l<0>(mine[k]); sample(tv, acc[4 * k + 0]); }
-        { const TapL tv = quad_bcast_l<1>(mine[k]); sample(tv, acc[4 * k + 1]); }
-        { const TapL tv = quad_bcast_l<2>(mine[k]); sample(tv, acc[4 * k + 2]); }
-        { const TapL tv = quad_bcast_l<3>(mine[k]); sample(tv, acc[4 * k + 3]); }
+        { const TapL tv = quad_bcast_l<0>(mine[k]); sample(tv, acc[4 * k + 0], std::false_type{}); }
+        { const TapL tv = quad_bcast_l<1>(mine[k]); sample(tv, acc[4 * k + 1], std::false_type{}); }
+        { const TapL tv = quad_bcast_l<2>(mine[k]); sample(tv, acc[4 * k + 2], std::false_type{}); }
+        { const TapL tv = quad_bcast_l<3>(mine[k]); sample(tv, acc[4 * k + 3], std::false_type{}); }
+        if constexpr (Q5) sample(mine[k], accx[k], std::true_type{});
       }
     }
 #ifdef FVP_TRI_BLK_NOMAX          // (ablation variants, tools/build_variant.sh: wrong results)
@@ -678,7 +694,7 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
     for (int i = t; i < ncell; i += NT) cxy[i] = 0;
     __syncthreads();
 #pragma unroll
-    for (int n = 0; n < NVL; ++n)
+    for (int n = 0; n < NVA; ++n)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int ch = 16 * n + 4 * q + c;
@@ -700,6 +716,31 @@ k_project_triplane_blk(const float* __restrict__ heat_cl, const Cam* __restrict_
         mi = imax(mi, dpp_i<0x128>(mi));
         if (zs == 0 && mi > 0 && ch < JP) cxy[(xx * kBY + yy) * JPp + ch] = mi;
       }
+    if constexpr (Q5) {
+      // the fifth quad: this lane holds channels 16-19 of voxel i = 4 k + q (z = zs + 4 i) of its column; the column's x-y
+      // maximum is over all 16 lanes of the DPP row (q and zs)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ch = 16 + c;
+        float mz = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < OWN; ++kk) {
+          const float val = fmaxf(accx[kk][0][c], 0.0f);
+          mz = fmaxf(mz, val);
+          if (val > 0.0f) {
+            const int z = zs + 4 * (4 * kk + q);
+            atomicMax(&cxz[(xx * BZ + z) * JPp + ch], __float_as_int(val));
+            atomicMax(&cyz[(yy * BZ + z) * JPp + ch], __float_as_int(val));
+          }
+        }
+        int mi = __float_as_int(mz);
+        mi = imax(mi, dpp_i<0x121>(mi));
+        mi = imax(mi, dpp_i<0x122>(mi));
+        mi = imax(mi, dpp_i<0x124>(mi));
+        mi = imax(mi, dpp_i<0x128>(mi));
+        if (zs == 0 && q == 0 && mi > 0) cxy[(xx * kBY + yy) * JPp + ch] = mi;
+      }
+    }
     __syncthreads();
     const int lz0 = gz0 - tl2;
     for (int i = t; i < kBX * kBY * J; i += NT) {

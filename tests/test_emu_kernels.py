@@ -367,7 +367,7 @@ def test_fused_projection_one_tile_two_tile_and_gather_rectangles(emu_lib, monke
 
 
 
-@pytest.mark.parametrize("J,V", [(1, 3), (32, 3), (21, 3), (15, 3), (5, 1), (5, 8)])
+@pytest.mark.parametrize("J,V", [(1, 3), (32, 3), (21, 3), (15, 3), (17, 3), (19, 3), (5, 1), (5, 8)])
 def test_joint_and_view_count_extremes(emu_lib, J, V):
     """The limits include/fvp.h states (FVP_MAX_JOINTS = 32, FVP_MAX_VIEWS = 8) and the minima (one joint, one view; J = 21
     -> JP = 24, a channel padding none of the shipped configs has): the whole forward on the miniature shape against the

@@ -18,7 +18,8 @@ LIB = os.path.join(ROOT, "faster-voxelpose_amd", "libfvp_hip.so")
 ALTERNATE_FORMS = {
     # the UNCACHED 20-channel block form (coordinate cache switched off or above its 2 GB limit - no BASELINE configuration):
     # 4 SGPR spills in the set-up code in front of the loops (the camera table of a view is 24 scalars)
-    "k_project_triplane_blk<2, false, false>": (4, 0),
+    "k_project_triplane_blk<2, false, false, false>": (4, 0),
+    "k_project_triplane_blk<2, false, false, true>": (2, 0),      # its five-quad form (JP = 20, round 6)
     # soft-argmax + WeightNet: 24 SGPR spills in the feature loop.  The three spill-free forms tried in round 5 (template
     # on F without the predicates + scalars re-read behind an opaque pointer, per window / per feature group / chained to an
     # earlier feature's result) measured 252-299 us against 177 us per launch: the spills are the faster code.
@@ -52,7 +53,7 @@ def test_library_holds_the_expected_kernels(rows):
         assert k not in names, k
     assert len(rows) >= 150
     for k in ("k_conv_wino<2, 4, 8, 2, true, false, 2>", "k_conv_reg<128, 4, 1, true>", "k_conv_dma<7, 7, 1, 4, true",
-              "k_project_triplane_blk<1, true, false>", "k_project_whole_q", "k_conv1d_fused", "k_softargmax_weightnet",
+              "k_project_triplane_blk<1, true, false, false>", "k_project_triplane_blk<2, true, false, true>", "k_project_whole_q", "k_conv1d_fused", "k_softargmax_weightnet",
               "k_bb_conv_dma", "k_conv7<64, 4, 4>", "k_conv7<64, 5, 4>", "k_conv7<128, 4, 4>"):
         assert k in names, k
 
