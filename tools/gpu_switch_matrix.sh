@@ -22,3 +22,5 @@ run FVP_WINO_W16=1 FVP_WINO_HALF=2
 run FVP_TRI_ZRES=1
 run FVP_CONV_NO_K7=1
 run FVP_BB_NO_FUSE_STEM=1 FVP_BB_NO_FUSE_BLOCK=1
+run FVP_TRI_NO_Q5=1
+run FVP_WINO_GENERIC=1
