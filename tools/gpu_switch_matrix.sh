@@ -3,7 +3,7 @@
 root="${GRAFT_REPO_ROOT:-$(pwd)}"; cd "$root"; export TMPDIR=/tmp
 [[ -f tests/diag/libfvp_hip_diag.so ]] || tests/diag/build_diag.sh >/dev/null
 # FVP_TEST_DIAG_LIB=1: tests/conftest.py points the package at the diagnostics build (the shipped library ignores FVP_* switches)
-run() { echo -n "$* : "; env FVP_TEST_DIAG_LIB=1 "$@" timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -x 2>&1 | tail -1; }
+run() { echo -n "$* : "; env FVP_TEST_DIAG_LIB=1 "$@" timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -x 2>&1 | grep -E "passed|failed|error" | tail -1; }
 run X=1
 run FVP_TRIPLANE_STAGED=1
 run FVP_TRIPLANE_QUAD=1
