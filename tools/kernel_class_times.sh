@@ -17,7 +17,7 @@ meta={"seq":[seq]*B}
 model = FV.get(cfg).to(dev); model.load_state_dict(S.fill_state_dict(model.state_dict(), seed=7))
 if os.environ.get("FVP_NO_FINE_CACHE"): model.engine.cache_fine_grid = False
 lib = capi.load()
-names = {capi.K_PROJECT_WHOLE: "project_whole", capi.K_PROJECT_TRIPLANE: "project_triplane", capi.K_SOFTARGMAX:"softargmax", capi.K_OTHER:"other", capi.K_CONV:"conv", capi.K_CONV_WINO:"wino"}
+names = {capi.K_PROJECT_WHOLE: "project_whole", capi.K_PROJECT_TRIPLANE: "project_triplane", capi.K_SOFTARGMAX:"softargmax", capi.K_OTHER:"other", capi.K_CONV:"conv", capi.K_CONV_WINO:"wino", capi.K_CONV_WINO_SMALL:"wino_sub_chip"}
 with torch.no_grad():
     for _ in range(3): out = model(meta=meta, input_heatmaps=heat, cameras=cams, resize_transform=rt)
     torch.cuda.synchronize()
